@@ -1,0 +1,127 @@
+/*
+ * yelprec_engine.h — C ABI of the MI355X (gfx950) engine for the BPR / NGCF / CDAE
+ * hot path of twndus/YelpRecommendation.
+ *
+ * The reference has no FFI: its "operator interface" for this path is the set of
+ * ATen ops its Python issues.  Each entry point below replaces one
+ * such op group and cites the reference call site it stands in for.  The Python
+ * classes in yelprecommendation_amd/ (same names and signatures as the reference's
+ * models/ and trainers/ modules) are the only callers; INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the
+ *     caller (PyTorch allocates tables, gradients, optimizer state, workspaces);
+ *     the library never allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); launches are
+ *     asynchronous on it; functions are stateless and re-entrant;
+ *   - tables are row-major contiguous float32 [rows, D]; indices are int64 (what the
+ *     reference's DataLoader yields: data/datasets/mf_dataset.py:26-31);
+ *   - supported embedding widths D: 16, 32, 64, 128 (YR_ERR_UNSUPPORTED otherwise);
+ *   - return value: 0 on success, a positive hipError_t if a launch failed, or a
+ *     negative YR_ERR_* for a rejected argument.  Nothing throws.
+ *   - `err_flag` (int32, device, may be NULL): kernels that consume indices OR a
+ *     bit into it when they meet an out-of-range index (YR_FLAG_*), skip that
+ *     element and carry on, instead of faulting the GPU.
+ */
+#ifndef YELPREC_ENGINE_H
+#define YELPREC_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YR_ENGINE_VERSION 1
+
+#define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
+#define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
+
+#define YR_FLAG_BAD_USER 1
+#define YR_FLAG_BAD_ITEM 2
+
+#define YR_OPT_ADAM  0 /* torch.optim.Adam  : grad += wd * p               */
+#define YR_OPT_ADAMW 1 /* torch.optim.AdamW : p *= 1 - lr * wd (decoupled) */
+
+/* Number of float32 partial sums a loss-producing kernel writes (one per workgroup
+ * slot, unused slots written as 0).  Callers size `loss_partials` with this.      */
+#define YR_LOSS_PARTIALS 2048
+
+/* Load check: returns YR_ENGINE_VERSION. */
+int yr_engine_version(void);
+
+/* The gfx arch string the code objects were built for ("gfx950"). */
+const char *yr_engine_arch(void);
+
+/* ---------------------------------------------------------------------------
+ * MatrixFactorization.forward                      (reference models/mf.py:20-23)
+ *   out[b] = sum_d U[user[b], d] * I[item[b], d]
+ * replaces: 2 x nn.Embedding gather + torch.mul + torch.sum(dim=1).
+ * ------------------------------------------------------------------------- */
+int yr_mf_score(const float *U, const float *I,
+                const int64_t *user, const int64_t *item,
+                int64_t B, int D, int64_t num_users, int64_t num_items,
+                float *out, int32_t *err_flag, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * autograd of MatrixFactorization.forward  (triggered at trainers/mf_trainer.py:111)
+ *   gradU[user[b]] += gout[b] * I[item[b]];  gradI[item[b]] += gout[b] * U[user[b]]
+ * replaces: mul/sum backward + 2 x embedding_dense_backward (index_add_ into the
+ * dense [rows, D] gradient).  gradU / gradI are ACCUMULATED into (caller zero-fills,
+ * as optimizer.zero_grad() / autograd do in the reference).
+ * ------------------------------------------------------------------------- */
+int yr_mf_score_backward(const float *U, const float *I,
+                         const int64_t *user, const int64_t *item, const float *gout,
+                         int64_t B, int D, int64_t num_users, int64_t num_items,
+                         float *gradU, float *gradI, int32_t *err_flag, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * One fused BPR forward + backward over a batch of (user, pos, neg) triplets
+ *   (reference trainers/mf_trainer.py:106-111 = models/mf.py:20-23 twice,
+ *    loss.py:25-27, loss.backward()).
+ *   x_b   = U[u_b] . (I[p_b] - I[n_b])
+ *   loss  = mean_b softplus(-x_b)                      -> loss_partials (unscaled sums)
+ *   g_b   = -sigmoid(-x_b) * inv_batch
+ *   gradU[u_b] += g_b (I[p_b] - I[n_b]);  gradI[p_b] += g_b U[u_b];  gradI[n_b] -= g_b U[u_b]
+ * `inv_batch` is 1/B for one GPU and 1/B_global when the batch is sharded by user
+ * across ranks (keeps loss.py:27's mean over the global batch).
+ * `gradU`/`gradI` may both be NULL: forward + loss only (MFTrainer.validate,
+ * mf_trainer.py:118-132).  loss_partials: YR_LOSS_PARTIALS floats, fully overwritten.
+ * ------------------------------------------------------------------------- */
+int yr_bpr_mf_fwd_bwd(const float *U, const float *I,
+                      const int64_t *user, const int64_t *pos, const int64_t *neg,
+                      int64_t B, int D, int64_t num_users, int64_t num_items,
+                      float inv_batch, float *gradU, float *gradI,
+                      float *loss_partials, int32_t *err_flag, void *stream);
+
+/* loss_out[0] = scale * sum(loss_partials);  if loss_accum: loss_accum[0] += same.
+ * (`train_loss += loss.item()` of mf_trainer.py:114 without the per-step host sync;
+ *  loss_accum is float64 like the Python float it replaces.)                        */
+int yr_loss_finalize(const float *loss_partials, float scale,
+                     float *loss_out, double *loss_accum, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Dense Adam / AdamW step over n float32 elements
+ *   (reference trainers/base_trainer.py:34-38 -> torch.optim.Adam/AdamW.step,
+ *    torch defaults; the CPU single-tensor formula, see oracle/adam.py).
+ * Hyper-parameters are doubles (torch keeps them as Python floats); derived scalars
+ * (1 - beta1, 1 - beta2, 1 - lr*wd) are formed in double and rounded to float32 once,
+ * as torch does when a Python scalar meets a float32 tensor.  The caller supplies
+ *   step_size = lr / (1 - beta1^t),  bc2_sqrt = sqrt(1 - beta2^t).
+ * zero_grad != 0 also clears g (the next step's optimizer.zero_grad()).
+ * n must be a multiple of 4 and all pointers 16-byte aligned.
+ * ------------------------------------------------------------------------- */
+int yr_adam_dense(float *p, float *g, float *m, float *v, int64_t n,
+                  double lr, double step_size, double bc2_sqrt,
+                  double beta1, double beta2, double eps, double weight_decay,
+                  int mode, int zero_grad, void *stream);
+
+/* Dense SGD (no momentum): p -= lr * (g + wd * p)   (base_trainer.py:39-40). */
+int yr_sgd_dense(float *p, float *g, int64_t n, double lr, double weight_decay,
+                 int zero_grad, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YELPREC_ENGINE_H */

@@ -1,0 +1,128 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the NumPy oracle on seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import adam as oadam
+from oracle import bpr_mf as obpr
+
+pytestmark = pytest.mark.gpu
+
+# float32 parity: the kernels reassociate sums (wave shuffles, float atomics), so
+# results agree to rounding, not bitwise.
+RTOL, ATOL = 2e-5, 2e-6
+
+
+def _tables(rs, nu, ni, d):
+    U = (rs.standard_normal((nu, d)) * 0.3).astype(np.float32)
+    I = (rs.standard_normal((ni, d)) * 0.3).astype(np.float32)
+    return U, I
+
+
+@pytest.mark.parametrize("d", [16, 32, 64, 128])
+@pytest.mark.parametrize("B", [1, 63, 256, 1000, 5000])
+def test_mf_score(device, d, B):
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(B + d)
+    nu, ni = 301, 517
+    U, I = _tables(rs, nu, ni, d)
+    u = rs.randint(0, nu, size=B).astype(np.int64)
+    i = rs.randint(0, ni, size=B).astype(np.int64)
+    out = engine.mf_score(torch.from_numpy(U).to(device), torch.from_numpy(I).to(device),
+                          torch.from_numpy(u).to(device), torch.from_numpy(i).to(device))
+    np.testing.assert_allclose(out.cpu().numpy(), obpr.forward(U, I, u, i), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("d", [16, 32, 64, 128])
+@pytest.mark.parametrize("B", [1, 7, 256, 777, 4096])
+def test_bpr_fwd_bwd(device, d, B):
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(1000 + B + d)
+    nu, ni = 97, 131            # small tables => many duplicate rows inside the batch
+    U, I = _tables(rs, nu, ni, d)
+    u = rs.randint(0, nu, size=B).astype(np.int64)
+    p = rs.randint(0, ni, size=B).astype(np.int64)
+    n = rs.randint(0, ni, size=B).astype(np.int64)
+    loss, gU, gI = obpr.loss_and_grads(U, I, u, p, n)
+
+    dU, dI = torch.from_numpy(U).to(device), torch.from_numpy(I).to(device)
+    gradU, gradI = torch.zeros_like(dU), torch.zeros_like(dI)
+    partials = torch.full((engine.LOSS_PARTIALS,), 7.0, dtype=torch.float32, device=device)
+    flag = engine.new_error_flag(device)
+    engine.bpr_mf_fwd_bwd(dU, dI, *(torch.from_numpy(a).to(device) for a in (u, p, n)),
+                          gradU, gradI, partials, err_flag=flag)
+    out = engine.loss_finalize(partials, 1.0 / B)
+    assert int(flag.item()) == 0
+    np.testing.assert_allclose(out.item(), loss, rtol=1e-5)
+    np.testing.assert_allclose(gradU.cpu().numpy(), gU, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(gradI.cpu().numpy(), gI, rtol=1e-4, atol=1e-6)
+
+    # forward-only mode (validate): same loss, no gradient buffers
+    partials.fill_(3.0)
+    engine.bpr_mf_fwd_bwd(dU, dI, *(torch.from_numpy(a).to(device) for a in (u, p, n)), None, None, partials)
+    np.testing.assert_allclose(engine.loss_finalize(partials, 1.0 / B).item(), loss, rtol=1e-5)
+
+
+def test_bpr_empty_and_bad_index(device):
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(5)
+    U, I = _tables(rs, 10, 12, 64)
+    dU, dI = torch.from_numpy(U).to(device), torch.from_numpy(I).to(device)
+    gradU, gradI = torch.zeros_like(dU), torch.zeros_like(dI)
+    partials = torch.ones(engine.LOSS_PARTIALS, dtype=torch.float32, device=device)
+    e = torch.zeros(0, dtype=torch.int64, device=device)
+    engine.bpr_mf_fwd_bwd(dU, dI, e, e, e, gradU, gradI, partials)        # empty batch
+    assert float(partials.sum().item()) == 0.0 and float(gradU.abs().sum().item()) == 0.0
+    u = torch.tensor([0, 3, 10, 2], dtype=torch.int64, device=device)      # 10 is out of range
+    p = torch.tensor([1, 2, 3, 12], dtype=torch.int64, device=device)      # 12 is out of range
+    n = torch.tensor([4, 5, 6, -1], dtype=torch.int64, device=device)      # -1 is out of range
+    flag = engine.new_error_flag(device)
+    engine.bpr_mf_fwd_bwd(dU, dI, u, p, n, gradU, gradI, partials, err_flag=flag)
+    assert int(flag.item()) == (engine.FLAG_BAD_USER | engine.FLAG_BAD_ITEM)
+    # the two valid triplets still contributed, scaled by inv_batch = 1/4 (not 1/2)
+    _, gU, gI = obpr.loss_and_grads(U, I, np.array([0, 3]), np.array([1, 2]), np.array([4, 5]))
+    np.testing.assert_allclose(gradU.cpu().numpy(), gU * 0.5, rtol=1e-4, atol=1e-7)
+    with pytest.raises(IndexError):
+        engine.raise_on_flag(flag)
+
+
+@pytest.mark.parametrize("mode", ["adam", "adamw", "adam_wd"])
+def test_adam_dense(device, mode):
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(11)
+    n = 4 * 12345
+    p = rs.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    dp, dm, dv = (torch.from_numpy(a.copy()).to(device) for a in (p, m, v))
+    wd = 0.0 if mode == "adam" else 1e-2
+    for step in range(1, 6):
+        g = (rs.standard_normal(n) * (rs.rand(n) < 0.3)).astype(np.float32)   # mostly-zero dense grad
+        dg = torch.from_numpy(g.copy()).to(device)
+        oadam.adam_update(p, g, m, v, step, 1e-3, weight_decay=wd, decoupled=(mode == "adamw"))
+        engine.adam_dense(dp, dg, dm, dv, step, 1e-3, weight_decay=wd, decoupled=(mode == "adamw"),
+                          zero_grad=True)
+        assert float(dg.abs().sum().item()) == 0.0
+    np.testing.assert_allclose(dp.cpu().numpy(), p, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(dm.cpu().numpy(), m, rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(dv.cpu().numpy(), v, rtol=1e-5, atol=1e-12)
+
+
+def test_sgd_dense(device):
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(12)
+    n = 4096
+    p = rs.standard_normal(n).astype(np.float32)
+    g = rs.standard_normal(n).astype(np.float32)
+    dp, dg = torch.from_numpy(p.copy()).to(device), torch.from_numpy(g.copy()).to(device)
+    oadam.sgd_update(p, g, 0.05, 1e-3)
+    engine.sgd_dense(dp, dg, 0.05, 1e-3)
+    np.testing.assert_allclose(dp.cpu().numpy(), p, rtol=1e-6, atol=1e-7)
+
+
+def test_cpu_tensor_rejected(device):
+    from yelprecommendation_amd import engine
+    from yelprecommendation_amd._lib import EngineError
+    with pytest.raises(EngineError):
+        engine.mf_score(torch.zeros(4, 64), torch.zeros(4, 64), torch.zeros(2, dtype=torch.int64),
+                        torch.zeros(2, dtype=torch.int64))

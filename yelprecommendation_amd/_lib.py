@@ -1,0 +1,78 @@
+"""ctypes binding of the C-ABI engine (include/yelprec_engine.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (or
+``make -C yelprecommendation_amd/csrc``) as
+``yelprecommendation_amd/libyelprec_engine.so``.  There is NO fallback: if the
+library is missing or an entry point is absent, loading raises, and every op in
+:mod:`yelprecommendation_amd.engine` raises with it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
+ENGINE_VERSION = 1
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+_f = C.c_float
+_d = C.c_double
+
+# name -> argtypes, mirroring include/yelprec_engine.h declaration by declaration
+SIGNATURES = {
+    "yr_engine_version": [],
+    "yr_engine_arch": [],
+    "yr_mf_score": [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _p],
+    "yr_mf_score_backward": [_p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _p, _p],
+    "yr_bpr_mf_fwd_bwd": [_p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _f, _p, _p, _p, _p, _p],
+    "yr_loss_finalize": [_p, _f, _p, _p, _p],
+    "yr_adam_dense": [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _d, _d, _int, _int, _p],
+    "yr_sgd_dense": [_p, _p, _i64, _d, _d, _int, _p],
+}
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises EngineError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            f"HIP engine library not found at {LIB_PATH}. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C yelprecommendation_amd/csrc`. There is no CPU/PyTorch fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing ROCm runtime etc.
+        raise EngineError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise EngineError(f"{LIB_PATH} does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "yr_engine_arch" else C.c_int
+    v = lib.yr_engine_version()
+    if v != ENGINE_VERSION:
+        raise EngineError(f"engine ABI version {v} != expected {ENGINE_VERSION}; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status == 0:
+        return
+    if status == -1:
+        raise EngineError(f"{what}: unsupported configuration (embedding width must be 16/32/64/128)")
+    if status == -2:
+        raise EngineError(f"{what}: bad argument (null pointer, negative size or misaligned buffer)")
+    raise EngineError(f"{what}: HIP error {status}")

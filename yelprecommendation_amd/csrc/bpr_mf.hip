@@ -1,0 +1,334 @@
+// BPR matrix-factorisation kernels for gfx950 (MI355X, CDNA4; wave = 64).
+//
+// Replaces the ATen op chain the reference issues per batch
+// (reference trainers/mf_trainer.py:104-111 -> models/mf.py:20-23, loss.py:25-27,
+// autograd's embedding_dense_backward) with one gather + score + loss +
+// scatter-add kernel.  HBM/Infinity-Cache bound byte work: no MFMA here.
+//
+// Layout: tables are row-major float32 [rows, D].  One row lives on LPR = min(D,64)
+// lanes (element l + 64*j on lane l), so every load, store and float atomic of a row
+// is one or two wave-instructions over 256 (128 for D=32, 64 for D=16) contiguous
+// bytes — the access shape the memory-side float atomics sustain their full rate on.
+// The (u, i, j) triplets of a tile are staged through LDS once (coalesced 8-byte
+// loads, range-checked, narrowed to int32) and then broadcast-read by the waves.
+#include "common.h"
+
+namespace yr {
+
+constexpr int kTile = kBlock;   // triplets staged per workgroup iteration
+constexpr int kUnroll = 4;      // row groups in flight per wave
+
+template <int D>
+struct Row {
+  float e[RowGeom<D>::EPL];
+};
+
+template <int D>
+__device__ __forceinline__ Row<D> load_row(const float* __restrict__ T, int32_t r, int l) {
+  Row<D> x;
+  const float* p = T + (int64_t)r * D + l;
+#pragma unroll
+  for (int j = 0; j < RowGeom<D>::EPL; ++j) x.e[j] = p[j * kWave];
+  return x;
+}
+
+// Stage one tile of triplets into LDS as int32, -1 for tail / out-of-range entries.
+template <int NIDX>
+__device__ __forceinline__ int stage_indices(int32_t (*s_idx)[kTile], const int64_t* const* idx,
+                                             const int64_t* limit, const int* flag_bit,
+                                             int64_t tile, int64_t B) {
+  const int64_t b = tile * kTile + threadIdx.x;
+  int32_t v[NIDX];
+  int bad = 0;
+#pragma unroll
+  for (int k = 0; k < NIDX; ++k) v[k] = -1;
+  if (b < B) {
+    int64_t raw[NIDX];
+#pragma unroll
+    for (int k = 0; k < NIDX; ++k) {
+      raw[k] = idx[k][b];
+      if ((uint64_t)raw[k] >= (uint64_t)limit[k]) bad |= flag_bit[k];
+    }
+    if (!bad) {
+#pragma unroll
+      for (int k = 0; k < NIDX; ++k) v[k] = (int32_t)raw[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NIDX; ++k) s_idx[k][threadIdx.x] = v[k];
+  return bad;
+}
+
+// ---------------------------------------------------------------------------
+// fused forward + loss (+ backward scatter-add when BWD)
+// ---------------------------------------------------------------------------
+template <int D, bool BWD>
+__global__ __launch_bounds__(kBlock) void bpr_fwd_bwd_kernel(
+    const float* __restrict__ U, const float* __restrict__ I,
+    const int64_t* __restrict__ user, const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
+    int64_t B, int64_t num_users, int64_t num_items, float inv_batch,
+    float* __restrict__ gradU, float* __restrict__ gradI,
+    float* __restrict__ loss_partials, int32_t* __restrict__ err_flag) {
+  using G = RowGeom<D>;
+  __shared__ int32_t s_idx[3][kTile];
+  __shared__ float s_red[kWavesPerBlock];
+
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int sub = lane / G::LPR, l = lane % G::LPR;
+  const int64_t* idx[3] = {user, pos, neg};
+  const int64_t limit[3] = {num_users, num_items, num_items};
+  const int flag_bit[3] = {YR_FLAG_BAD_USER, YR_FLAG_BAD_ITEM, YR_FLAG_BAD_ITEM};
+
+  float loss_acc = 0.0f;
+  int bad = 0;
+  const int64_t ntiles = (B + kTile - 1) / kTile;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    bad |= stage_indices<3>(s_idx, idx, limit, flag_bit, tile, B);
+    __syncthreads();
+
+    // this wave owns triplets [wave*64, wave*64+64) of the tile
+    for (int k = 0; k < kWave; k += G::RPW * kUnroll) {
+      int32_t uu[kUnroll], pp[kUnroll], nn[kUnroll];
+      Row<D> ru[kUnroll], rp[kUnroll], rn[kUnroll];
+#pragma unroll
+      for (int q = 0; q < kUnroll; ++q) {
+        const int t = wave * kWave + k + q * G::RPW + sub;
+        uu[q] = s_idx[0][t];
+        pp[q] = s_idx[1][t];
+        nn[q] = s_idx[2][t];
+      }
+#pragma unroll
+      for (int q = 0; q < kUnroll; ++q) {
+        // invalid entries read row 0 (harmless) and are masked out below
+        ru[q] = load_row<D>(U, max(uu[q], 0), l);
+        rp[q] = load_row<D>(I, max(pp[q], 0), l);
+        rn[q] = load_row<D>(I, max(nn[q], 0), l);
+      }
+#pragma unroll
+      for (int q = 0; q < kUnroll; ++q) {
+        const bool valid = uu[q] >= 0;
+        float diff[G::EPL], part = 0.0f;
+#pragma unroll
+        for (int j = 0; j < G::EPL; ++j) {
+          diff[j] = rp[q].e[j] - rn[q].e[j];
+          part = fmaf(ru[q].e[j], diff[j], part);
+        }
+        const float x = group_sum<G::LPR>(part);   // s+ - s- = u . (i+ - i-)
+        if (valid && l == 0) loss_acc += softplus_neg(x);
+        if (BWD) {
+          const float g = -sigmoid_neg(x) * inv_batch;
+          if (valid) {
+            float* du = gradU + (int64_t)uu[q] * D + l;
+            float* dp = gradI + (int64_t)pp[q] * D + l;
+            float* dn = gradI + (int64_t)nn[q] * D + l;
+#pragma unroll
+            for (int j = 0; j < G::EPL; ++j) {
+              const float gu = g * ru[q].e[j];
+              atomicAdd(du + j * kWave, g * diff[j]);
+              atomicAdd(dp + j * kWave, gu);
+              atomicAdd(dn + j * kWave, -gu);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  const float total = block_sum(loss_acc, s_red);
+  if (threadIdx.x == 0) loss_partials[blockIdx.x] = total;
+  if (bad && err_flag) atomicOr(err_flag, bad);
+}
+
+// zero the loss-partial slots no workgroup owns
+__global__ void clear_tail_kernel(float* p, int from, int to) {
+  const int i = from + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < to) p[i] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------
+// MatrixFactorization.forward and its backward
+// ---------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(kBlock) void mf_score_kernel(
+    const float* __restrict__ U, const float* __restrict__ I,
+    const int64_t* __restrict__ user, const int64_t* __restrict__ item,
+    int64_t B, int64_t num_users, int64_t num_items,
+    float* __restrict__ out, int32_t* __restrict__ err_flag) {
+  using G = RowGeom<D>;
+  __shared__ int32_t s_idx[2][kTile];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int sub = lane / G::LPR, l = lane % G::LPR;
+  const int64_t* idx[2] = {user, item};
+  const int64_t limit[2] = {num_users, num_items};
+  const int flag_bit[2] = {YR_FLAG_BAD_USER, YR_FLAG_BAD_ITEM};
+  int bad = 0;
+  const int64_t ntiles = (B + kTile - 1) / kTile;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    bad |= stage_indices<2>(s_idx, idx, limit, flag_bit, tile, B);
+    __syncthreads();
+    for (int k = 0; k < kWave; k += G::RPW * kUnroll) {
+      int32_t uu[kUnroll], ii[kUnroll];
+      Row<D> ru[kUnroll], ri[kUnroll];
+#pragma unroll
+      for (int q = 0; q < kUnroll; ++q) {
+        const int t = wave * kWave + k + q * G::RPW + sub;
+        uu[q] = s_idx[0][t];
+        ii[q] = s_idx[1][t];
+      }
+#pragma unroll
+      for (int q = 0; q < kUnroll; ++q) {
+        ru[q] = load_row<D>(U, max(uu[q], 0), l);
+        ri[q] = load_row<D>(I, max(ii[q], 0), l);
+      }
+#pragma unroll
+      for (int q = 0; q < kUnroll; ++q) {
+        float part = 0.0f;
+#pragma unroll
+        for (int j = 0; j < G::EPL; ++j) part = fmaf(ru[q].e[j], ri[q].e[j], part);
+        const float s = group_sum<G::LPR>(part);
+        const int64_t b = tile * kTile + wave * kWave + k + q * G::RPW + sub;
+        if (l == 0 && b < B) out[b] = uu[q] >= 0 ? s : 0.0f;
+      }
+    }
+    __syncthreads();
+  }
+  if (bad && err_flag) atomicOr(err_flag, bad);
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void mf_score_backward_kernel(
+    const float* __restrict__ U, const float* __restrict__ I,
+    const int64_t* __restrict__ user, const int64_t* __restrict__ item,
+    const float* __restrict__ gout, int64_t B, int64_t num_users, int64_t num_items,
+    float* __restrict__ gradU, float* __restrict__ gradI, int32_t* __restrict__ err_flag) {
+  using G = RowGeom<D>;
+  __shared__ int32_t s_idx[2][kTile];
+  __shared__ float s_g[kTile];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int sub = lane / G::LPR, l = lane % G::LPR;
+  const int64_t* idx[2] = {user, item};
+  const int64_t limit[2] = {num_users, num_items};
+  const int flag_bit[2] = {YR_FLAG_BAD_USER, YR_FLAG_BAD_ITEM};
+  int bad = 0;
+  const int64_t ntiles = (B + kTile - 1) / kTile;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    bad |= stage_indices<2>(s_idx, idx, limit, flag_bit, tile, B);
+    {
+      const int64_t b = tile * kTile + threadIdx.x;
+      s_g[threadIdx.x] = b < B ? gout[b] : 0.0f;
+    }
+    __syncthreads();
+    for (int k = 0; k < kWave; k += G::RPW * kUnroll) {
+#pragma unroll
+      for (int q = 0; q < kUnroll; ++q) {
+        const int t = wave * kWave + k + q * G::RPW + sub;
+        const int32_t uu = s_idx[0][t], ii = s_idx[1][t];
+        const float g = s_g[t];
+        if (uu >= 0) {
+          const Row<D> ru = load_row<D>(U, uu, l);
+          const Row<D> ri = load_row<D>(I, ii, l);
+          float* du = gradU + (int64_t)uu * D + l;
+          float* di = gradI + (int64_t)ii * D + l;
+#pragma unroll
+          for (int j = 0; j < G::EPL; ++j) {
+            atomicAdd(du + j * kWave, g * ri.e[j]);
+            atomicAdd(di + j * kWave, g * ru.e[j]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (bad && err_flag) atomicOr(err_flag, bad);
+}
+
+// loss_out = scale * sum(partials)  (fixed order => bit-reproducible loss)
+__global__ __launch_bounds__(kBlock) void loss_finalize_kernel(const float* __restrict__ partials, float scale,
+                                                               float* __restrict__ loss_out,
+                                                               double* __restrict__ loss_accum) {
+  __shared__ float s_red[kWavesPerBlock];
+  float acc = 0.0f;
+  for (int i = threadIdx.x; i < YR_LOSS_PARTIALS; i += kBlock) acc += partials[i];
+  const float total = block_sum(acc, s_red);
+  if (threadIdx.x == 0) {
+    const float v = total * scale;
+    if (loss_out) loss_out[0] = v;
+    if (loss_accum) loss_accum[0] += (double)v;
+  }
+}
+
+}  // namespace yr
+
+using namespace yr;
+
+#define YR_DISPATCH_D(D, ...)                                 \
+  switch (D) {                                                \
+    case 16: { constexpr int kD = 16; __VA_ARGS__; } break;   \
+    case 32: { constexpr int kD = 32; __VA_ARGS__; } break;   \
+    case 64: { constexpr int kD = 64; __VA_ARGS__; } break;   \
+    case 128: { constexpr int kD = 128; __VA_ARGS__; } break; \
+    default: return YR_ERR_UNSUPPORTED;                       \
+  }
+
+extern "C" int yr_mf_score(const float* U, const float* I, const int64_t* user, const int64_t* item,
+                           int64_t B, int D, int64_t num_users, int64_t num_items, float* out,
+                           int32_t* err_flag, void* stream) {
+  if (B < 0 || num_users <= 0 || num_items <= 0) return YR_ERR_BADARG;
+  if (B == 0) return 0;
+  if (!U || !I || !user || !item || !out) return YR_ERR_BADARG;
+  const int grid = grid_for(B, kTile);
+  YR_DISPATCH_D(D, hipLaunchKernelGGL((mf_score_kernel<kD>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+                                       U, I, user, item, B, num_users, num_items, out, err_flag));
+  return launch_status();
+}
+
+extern "C" int yr_mf_score_backward(const float* U, const float* I, const int64_t* user, const int64_t* item,
+                                    const float* gout, int64_t B, int D, int64_t num_users, int64_t num_items,
+                                    float* gradU, float* gradI, int32_t* err_flag, void* stream) {
+  if (B < 0 || num_users <= 0 || num_items <= 0) return YR_ERR_BADARG;
+  if (B == 0) return 0;
+  if (!U || !I || !user || !item || !gout || !gradU || !gradI) return YR_ERR_BADARG;
+  const int grid = grid_for(B, kTile);
+  YR_DISPATCH_D(D, hipLaunchKernelGGL((mf_score_backward_kernel<kD>), dim3(grid), dim3(kBlock), 0,
+                                       (hipStream_t)stream, U, I, user, item, gout, B, num_users, num_items,
+                                       gradU, gradI, err_flag));
+  return launch_status();
+}
+
+extern "C" int yr_bpr_mf_fwd_bwd(const float* U, const float* I, const int64_t* user, const int64_t* pos,
+                                 const int64_t* neg, int64_t B, int D, int64_t num_users, int64_t num_items,
+                                 float inv_batch, float* gradU, float* gradI, float* loss_partials,
+                                 int32_t* err_flag, void* stream) {
+  if (B < 0 || num_users <= 0 || num_items <= 0 || !loss_partials) return YR_ERR_BADARG;
+  if ((gradU == nullptr) != (gradI == nullptr)) return YR_ERR_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  int grid = 0;
+  if (B > 0) {
+    if (!U || !I || !user || !pos || !neg) return YR_ERR_BADARG;
+    grid = grid_for(B, kTile);
+    if (gradU) {
+      YR_DISPATCH_D(D, hipLaunchKernelGGL((bpr_fwd_bwd_kernel<kD, true>), dim3(grid), dim3(kBlock), 0, s, U, I,
+                                           user, pos, neg, B, num_users, num_items, inv_batch, gradU, gradI,
+                                           loss_partials, err_flag));
+    } else {
+      YR_DISPATCH_D(D, hipLaunchKernelGGL((bpr_fwd_bwd_kernel<kD, false>), dim3(grid), dim3(kBlock), 0, s, U, I,
+                                           user, pos, neg, B, num_users, num_items, inv_batch, gradU, gradI,
+                                           loss_partials, err_flag));
+    }
+  }
+  if (grid < YR_LOSS_PARTIALS) {
+    const int rest = YR_LOSS_PARTIALS - grid;
+    hipLaunchKernelGGL(clear_tail_kernel, dim3((rest + kBlock - 1) / kBlock), dim3(kBlock), 0, s, loss_partials,
+                       grid, YR_LOSS_PARTIALS);
+  }
+  return launch_status();
+}
+
+extern "C" int yr_loss_finalize(const float* loss_partials, float scale, float* loss_out, double* loss_accum,
+                                void* stream) {
+  if (!loss_partials) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, loss_partials, scale,
+                     loss_out, loss_accum);
+  return launch_status();
+}

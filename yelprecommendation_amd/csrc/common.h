@@ -1,0 +1,71 @@
+// Shared device helpers for the gfx950 engine (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/yelprec_engine.h"
+
+namespace yr {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;            // 4 waves, one per SIMD
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kMaxGrid = YR_LOSS_PARTIALS;   // 256 CUs x 8 workgroups
+
+// Row geometry for an embedding width D: a row is spread over LPR lanes holding
+// EPL consecutive floats each, so one wave-instruction touches 64/LPR rows with
+// 64*EPL*4 contiguous bytes per row group (the shape the memory-side float
+// atomics run at full rate for: 256 contiguous bytes or two 128-B segments).
+template <int D>
+struct RowGeom {
+  static_assert(D == 16 || D == 32 || D == 64 || D == 128, "unsupported width");
+  static constexpr int LPR = D < 64 ? D : 64;   // lanes per row
+  static constexpr int EPL = D / LPR;           // elements per lane (1 or 2)
+  static constexpr int RPW = kWave / LPR;       // rows per wave pass
+};
+
+// sum over the LPR lanes of a row group; every lane of the group gets the total
+template <int LPR>
+__device__ __forceinline__ float group_sum(float x) {
+#pragma unroll
+  for (int m = LPR / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, kWave);
+  return x;
+}
+
+__device__ __forceinline__ float wave_sum(float x) { return group_sum<kWave>(x); }
+
+// softplus(-x) = -logsigmoid(x) = max(-x, 0) + log1p(exp(-|x|))
+__device__ __forceinline__ float softplus_neg(float x) {
+  return fmaxf(-x, 0.0f) + log1pf(expf(-fabsf(x)));
+}
+
+// sigmoid(-x), evaluated the way ATen's log_sigmoid_backward does
+__device__ __forceinline__ float sigmoid_neg(float x) {
+  const float z = expf(-fabsf(x));
+  return x < 0.0f ? 1.0f / (1.0f + z) : z / (1.0f + z);
+}
+
+// block-wide sum of one float per thread -> valid in thread 0
+__device__ __forceinline__ float block_sum(float x, float* smem /* >= kWavesPerBlock */) {
+  x = wave_sum(x);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (lane == 0) smem[wave] = x;
+  __syncthreads();
+  float t = 0.0f;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) t += smem[w];
+  }
+  return t;
+}
+
+inline int grid_for(int64_t work_items, int per_block) {
+  int64_t g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > kMaxGrid) g = kMaxGrid;
+  return (int)g;
+}
+
+inline int launch_status() { return (int)hipGetLastError(); }
+
+}  // namespace yr

@@ -1,0 +1,148 @@
+"""Thin host wrappers: torch tensors in, C-ABI calls out (include/yelprec_engine.h).
+
+PyTorch is plumbing here — it owns device memory and the stream; every arithmetic
+op of the hot path runs in the hand-written HIP kernels of ``csrc/``.  All tensors
+must live on a ROCm device (``tensor.is_cuda``); there is no CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import EngineError, check
+
+LOSS_PARTIALS = 2048        # YR_LOSS_PARTIALS
+FLAG_BAD_USER, FLAG_BAD_ITEM = 1, 2
+OPT_ADAM, OPT_ADAMW = 0, 1
+SUPPORTED_WIDTHS = (16, 32, 64, 128)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, dtype, name: str) -> int:
+    if not isinstance(t, torch.Tensor):
+        raise EngineError(f"{name}: expected a tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise EngineError(f"{name}: tensor is on {t.device}; the engine runs on MI355X only (no CPU fallback)")
+    if t.dtype != dtype:
+        raise EngineError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if not t.is_contiguous():
+        raise EngineError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _opt(t, dtype, name):
+    return None if t is None else _dev(t, dtype, name)
+
+
+def _table_dims(U: torch.Tensor, I: torch.Tensor):
+    if U.dim() != 2 or I.dim() != 2 or U.shape[1] != I.shape[1]:
+        raise EngineError(f"tables must be [rows, D] with equal D, got {tuple(U.shape)} / {tuple(I.shape)}")
+    return U.shape[0], I.shape[0], U.shape[1]
+
+
+def new_error_flag(device) -> torch.Tensor:
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def raise_on_flag(flag: torch.Tensor, what: str = "index"):
+    """Host-side check of an err_flag word (one device sync)."""
+    v = int(flag.item())
+    if v:
+        kinds = [k for b, k in ((FLAG_BAD_USER, "user"), (FLAG_BAD_ITEM, "item")) if v & b]
+        flag.zero_()
+        raise IndexError(f"{what}: out-of-range {' and '.join(kinds)} id(s) in a batch")
+
+
+def mf_score(U, I, user, item, out=None, err_flag=None):
+    """out[b] = U[user[b]] . I[item[b]]    (reference models/mf.py:20-23)."""
+    lib = _lib.load()
+    nu, ni, d = _table_dims(U, I)
+    B = user.numel()
+    if item.numel() != B:
+        raise EngineError("user and item index tensors differ in length")
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=U.device)
+    check(lib.yr_mf_score(_dev(U, torch.float32, "U"), _dev(I, torch.float32, "I"),
+                          _dev(user, torch.int64, "user"), _dev(item, torch.int64, "item"),
+                          B, d, nu, ni, _dev(out, torch.float32, "out"),
+                          _opt(err_flag, torch.int32, "err_flag"), _stream()), "yr_mf_score")
+    return out
+
+
+def mf_score_backward(U, I, user, item, gout, gradU, gradI, err_flag=None):
+    """gradU[user[b]] += gout[b] I[item[b]]; gradI[item[b]] += gout[b] U[user[b]]."""
+    lib = _lib.load()
+    nu, ni, d = _table_dims(U, I)
+    B = user.numel()
+    check(lib.yr_mf_score_backward(_dev(U, torch.float32, "U"), _dev(I, torch.float32, "I"),
+                                   _dev(user, torch.int64, "user"), _dev(item, torch.int64, "item"),
+                                   _dev(gout, torch.float32, "gout"), B, d, nu, ni,
+                                   _dev(gradU, torch.float32, "gradU"), _dev(gradI, torch.float32, "gradI"),
+                                   _opt(err_flag, torch.int32, "err_flag"), _stream()), "yr_mf_score_backward")
+
+
+def bpr_mf_fwd_bwd(U, I, user, pos, neg, gradU, gradI, loss_partials, inv_batch=None, err_flag=None):
+    """Fused BPR forward + loss (+ backward into dense gradU/gradI unless both None).
+
+    reference trainers/mf_trainer.py:106-111.  ``loss_partials`` (float32[LOSS_PARTIALS])
+    receives unscaled partial sums of softplus(-(s+ - s-)); see :func:`loss_finalize`.
+    """
+    lib = _lib.load()
+    nu, ni, d = _table_dims(U, I)
+    B = user.numel()
+    if pos.numel() != B or neg.numel() != B:
+        raise EngineError("user/pos/neg index tensors differ in length")
+    if loss_partials.numel() != LOSS_PARTIALS:
+        raise EngineError(f"loss_partials must hold {LOSS_PARTIALS} floats")
+    if inv_batch is None:
+        inv_batch = 1.0 / B if B else 0.0
+    if gradU is not None and (gradU.shape != U.shape or gradI.shape != I.shape):
+        raise EngineError("gradient buffers must match the table shapes")
+    check(lib.yr_bpr_mf_fwd_bwd(_dev(U, torch.float32, "U"), _dev(I, torch.float32, "I"),
+                                _dev(user, torch.int64, "user"), _dev(pos, torch.int64, "pos"),
+                                _dev(neg, torch.int64, "neg"), B, d, nu, ni, float(inv_batch),
+                                _opt(gradU, torch.float32, "gradU"), _opt(gradI, torch.float32, "gradI"),
+                                _dev(loss_partials, torch.float32, "loss_partials"),
+                                _opt(err_flag, torch.int32, "err_flag"), _stream()), "yr_bpr_mf_fwd_bwd")
+
+
+def loss_finalize(loss_partials, scale, loss_out=None, loss_accum=None):
+    """loss_out[0] = scale * sum(partials); loss_accum[0] (float64) += the same."""
+    lib = _lib.load()
+    if loss_out is None:
+        loss_out = torch.empty(1, dtype=torch.float32, device=loss_partials.device)
+    check(lib.yr_loss_finalize(_dev(loss_partials, torch.float32, "loss_partials"), float(scale),
+                               _dev(loss_out, torch.float32, "loss_out"),
+                               _opt(loss_accum, torch.float64, "loss_accum"), _stream()), "yr_loss_finalize")
+    return loss_out
+
+
+def adam_scalars(step: int, lr: float, beta1: float, beta2: float):
+    """Host doubles of torch's Adam step: (lr / (1 - b1^t), sqrt(1 - b2^t))."""
+    return lr / (1.0 - beta1 ** step), (1.0 - beta2 ** step) ** 0.5
+
+
+def adam_dense(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+               decoupled=False, zero_grad=False):
+    """Dense Adam/AdamW step in place (reference trainers/base_trainer.py:34-38)."""
+    lib = _lib.load()
+    n = p.numel()
+    if g.numel() != n or m.numel() != n or v.numel() != n:
+        raise EngineError("p/g/m/v sizes differ")
+    step_size, bc2_sqrt = adam_scalars(step, lr, beta1, beta2)
+    check(lib.yr_adam_dense(_dev(p, torch.float32, "p"), _dev(g, torch.float32, "g"),
+                            _dev(m, torch.float32, "m"), _dev(v, torch.float32, "v"), n,
+                            float(lr), float(step_size), float(bc2_sqrt), float(beta1), float(beta2),
+                            float(eps), float(weight_decay), OPT_ADAMW if decoupled else OPT_ADAM,
+                            1 if zero_grad else 0, _stream()), "yr_adam_dense")
+
+
+def sgd_dense(p, g, lr, weight_decay=0.0, zero_grad=False):
+    """Dense SGD step in place (reference trainers/base_trainer.py:39-40)."""
+    lib = _lib.load()
+    n = p.numel()
+    check(lib.yr_sgd_dense(_dev(p, torch.float32, "p"), _dev(g, torch.float32, "g"), n,
+                           float(lr), float(weight_decay), 1 if zero_grad else 0, _stream()), "yr_sgd_dense")
