@@ -102,6 +102,34 @@ int yr_loss_finalize(const float *loss_partials, float scale,
                      float *loss_out, double *loss_accum, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Masked row-wise top-k      (reference trainers/mf_trainer.py:163-178,
+ *                             trainers/ngcf_trainer.py:167-182, trainers/cdae_trainer.py:123-144)
+ *   for each row r of scores[nrows, ncols] (row pitch row_stride floats):
+ *     s[c] = mask_value for c in mask_idx[mask_ptr[r] .. mask_ptr[r+1])   (CSR over rows)
+ *     out[r, 0..k) = the k best column ids, score descending, id ascending on ties
+ * mask_value = -3.40282e+38 reproduces `pred[mask_items] = -3.40282e+38`; 0 reproduces
+ * CDAE's `pred * logical_not(input_mask)`.  mask_ptr may be NULL (no mask).  k <= 64.
+ * Rows shorter than k are padded with -1.  `scores` is not modified.
+ * replaces: numpy fancy-index store + argpartition + take_along_axis + argsort per user.
+ * ------------------------------------------------------------------------- */
+int yr_topk_masked(const float *scores, int64_t nrows, int64_t ncols, int64_t row_stride,
+                   const int64_t *mask_ptr, const int64_t *mask_idx, float mask_value,
+                   int k, int64_t *out, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * BPRLoss.forward / backward on score vectors        (reference loss.py:25-27)
+ *   loss = mean_b( -logsigmoid(pos[b] - neg[b]) )  -> loss_partials (unscaled sums;
+ *   finish with yr_loss_finalize(scale = 1/B));
+ *   gpos[b] = -sigmoid(-(pos[b]-neg[b])) * gout[0] * inv_batch,  gneg[b] = -gpos[b].
+ * For callers that keep the reference's three-call shape (two model() calls, then
+ * the loss); the fused yr_bpr_mf_fwd_bwd above never materialises pos/neg.
+ * ------------------------------------------------------------------------- */
+int yr_bpr_loss_fwd(const float *pos, const float *neg, int64_t B,
+                    float *loss_partials, void *stream);
+int yr_bpr_loss_bwd(const float *pos, const float *neg, const float *gout,
+                    float inv_batch, int64_t B, float *gpos, float *gneg, void *stream);
+
+/* ---------------------------------------------------------------------------
  * Dense Adam / AdamW step over n float32 elements
  *   (reference trainers/base_trainer.py:34-38 -> torch.optim.Adam/AdamW.step,
  *    torch defaults; the CPU single-tensor formula, see oracle/adam.py).
@@ -110,7 +138,7 @@ int yr_loss_finalize(const float *loss_partials, float scale,
  * as torch does when a Python scalar meets a float32 tensor.  The caller supplies
  *   step_size = lr / (1 - beta1^t),  bc2_sqrt = sqrt(1 - beta2^t).
  * zero_grad != 0 also clears g (the next step's optimizer.zero_grad()).
- * n must be a multiple of 4 and all pointers 16-byte aligned.
+ * Any n >= 0; all pointers must be 16-byte aligned (YR_ERR_BADARG otherwise).
  * ------------------------------------------------------------------------- */
 int yr_adam_dense(float *p, float *g, float *m, float *v, int64_t n,
                   double lr, double step_size, double bc2_sqrt,

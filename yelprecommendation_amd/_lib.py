@@ -29,6 +29,9 @@ SIGNATURES = {
     "yr_mf_score_backward": [_p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _p, _p],
     "yr_bpr_mf_fwd_bwd": [_p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _f, _p, _p, _p, _p, _p],
     "yr_loss_finalize": [_p, _f, _p, _p, _p],
+    "yr_topk_masked": [_p, _i64, _i64, _i64, _p, _p, _f, _int, _p, _p],
+    "yr_bpr_loss_fwd": [_p, _p, _i64, _p, _p],
+    "yr_bpr_loss_bwd": [_p, _p, _p, _f, _i64, _p, _p, _p],
     "yr_adam_dense": [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _d, _d, _int, _int, _p],
     "yr_sgd_dense": [_p, _p, _i64, _d, _d, _int, _p],
 }

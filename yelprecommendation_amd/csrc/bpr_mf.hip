@@ -332,3 +332,62 @@ extern "C" int yr_loss_finalize(const float* loss_partials, float scale, float* 
                      loss_out, loss_accum);
   return launch_status();
 }
+
+// ---------------------------------------------------------------------------
+// BPRLoss on its own (reference loss.py:25-27) for callers that keep the
+// reference's three-call shape  model(u,p), model(u,n), loss(pos, neg).
+// ---------------------------------------------------------------------------
+namespace yr {
+
+__global__ __launch_bounds__(kBlock) void bpr_loss_fwd_kernel(const float* __restrict__ pos,
+                                                              const float* __restrict__ neg, int64_t B,
+                                                              float* __restrict__ partials) {
+  __shared__ float s_red[kWavesPerBlock];
+  float acc = 0.0f;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += stride)
+    acc += softplus_neg(pos[b] - neg[b]);
+  const float total = block_sum(acc, s_red);
+  if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+
+// gpos[b] = -sigmoid(-(pos-neg)) * gout[0] * inv_batch ; gneg[b] = -gpos[b]
+__global__ __launch_bounds__(kBlock) void bpr_loss_bwd_kernel(const float* __restrict__ pos,
+                                                              const float* __restrict__ neg,
+                                                              const float* __restrict__ gout, float inv_batch,
+                                                              int64_t B, float* __restrict__ gpos,
+                                                              float* __restrict__ gneg) {
+  const float go = gout[0] * inv_batch;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += stride) {
+    const float g = -sigmoid_neg(pos[b] - neg[b]) * go;
+    gpos[b] = g;
+    gneg[b] = -g;
+  }
+}
+
+}  // namespace yr
+
+extern "C" int yr_bpr_loss_fwd(const float* pos, const float* neg, int64_t B, float* loss_partials, void* stream) {
+  if (B < 0 || !loss_partials) return YR_ERR_BADARG;
+  if (B > 0 && (!pos || !neg)) return YR_ERR_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = B > 0 ? grid_for(B, kBlock) : 0;
+  if (grid) hipLaunchKernelGGL(bpr_loss_fwd_kernel, dim3(grid), dim3(kBlock), 0, s, pos, neg, B, loss_partials);
+  if (grid < YR_LOSS_PARTIALS) {
+    const int rest = YR_LOSS_PARTIALS - grid;
+    hipLaunchKernelGGL(clear_tail_kernel, dim3((rest + kBlock - 1) / kBlock), dim3(kBlock), 0, s, loss_partials,
+                       grid, YR_LOSS_PARTIALS);
+  }
+  return launch_status();
+}
+
+extern "C" int yr_bpr_loss_bwd(const float* pos, const float* neg, const float* gout, float inv_batch, int64_t B,
+                               float* gpos, float* gneg, void* stream) {
+  if (B < 0) return YR_ERR_BADARG;
+  if (B == 0) return 0;
+  if (!pos || !neg || !gout || !gpos || !gneg) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(bpr_loss_bwd_kernel, dim3(grid_for(B, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, pos,
+                     neg, gout, inv_batch, B, gpos, gneg);
+  return launch_status();
+}

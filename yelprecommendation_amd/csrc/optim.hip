@@ -9,44 +9,60 @@
 
 namespace yr {
 
+struct AdamScalars {
+  float decay_mul, neg_step, bc2_sqrt, one_m_b1, beta2, one_m_b2, eps, wd;
+};
+
+template <bool DECOUPLED>
+__device__ __forceinline__ void adam_element(float& p, float grad, float& m, float& v, const AdamScalars& c) {
+  if (c.wd != 0.0f) {
+    if (DECOUPLED) p *= c.decay_mul;
+    else grad = grad + c.wd * p;
+  }
+  m = m + c.one_m_b1 * (grad - m);               // lerp_
+  v = v * c.beta2 + (c.one_m_b2 * grad) * grad;   // mul_, addcmul_
+  const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+  p = p + (c.neg_step * m) / denom;               // addcdiv_
+}
+
+// main body: 16 bytes per lane; elements [4*n4, n) are the scalar tail of block 0
 template <bool DECOUPLED, bool ZERO_GRAD>
-__global__ __launch_bounds__(kBlock) void adam_dense_kernel(float4* __restrict__ p, float4* __restrict__ g,
-                                                            float4* __restrict__ m, float4* __restrict__ v,
-                                                            int64_t n4, float decay_mul, float neg_step,
-                                                            float bc2_sqrt, float one_m_b1, float beta2,
-                                                            float one_m_b2, float eps, float wd) {
+__global__ __launch_bounds__(kBlock) void adam_dense_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v,
+                                                            int64_t n4, int64_t n, AdamScalars c) {
+  float4* p4 = reinterpret_cast<float4*>(p);
+  float4* g4 = reinterpret_cast<float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* v4 = reinterpret_cast<float4*>(v);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
-    float4 P = p[i], G = g[i], M = m[i], V = v[i];
-    float* pp = reinterpret_cast<float*>(&P);
-    float* gg = reinterpret_cast<float*>(&G);
-    float* mm = reinterpret_cast<float*>(&M);
-    float* vv = reinterpret_cast<float*>(&V);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float grad = gg[k];
-      if (wd != 0.0f) {
-        if (DECOUPLED) pp[k] *= decay_mul;
-        else grad = grad + wd * pp[k];
-      }
-      mm[k] = mm[k] + one_m_b1 * (grad - mm[k]);            // lerp_
-      vv[k] = vv[k] * beta2 + (one_m_b2 * grad) * grad;      // mul_, addcmul_
-      const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
-      pp[k] = pp[k] + (neg_step * mm[k]) / denom;            // addcdiv_
+    float4 P = p4[i], G = g4[i], M = m4[i], V = v4[i];
+    adam_element<DECOUPLED>(P.x, G.x, M.x, V.x, c);
+    adam_element<DECOUPLED>(P.y, G.y, M.y, V.y, c);
+    adam_element<DECOUPLED>(P.z, G.z, M.z, V.z, c);
+    adam_element<DECOUPLED>(P.w, G.w, M.w, V.w, c);
+    p4[i] = P;
+    m4[i] = M;
+    v4[i] = V;
+    if (ZERO_GRAD) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t i = 4 * n4 + threadIdx.x;
+    if (i < n) {
+      adam_element<DECOUPLED>(p[i], g[i], m[i], v[i], c);
+      if (ZERO_GRAD) g[i] = 0.0f;
     }
-    p[i] = P;
-    m[i] = M;
-    v[i] = V;
-    if (ZERO_GRAD) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
 template <bool ZERO_GRAD>
-__global__ __launch_bounds__(kBlock) void sgd_dense_kernel(float4* __restrict__ p, float4* __restrict__ g,
-                                                           int64_t n4, float lr, float wd) {
+__global__ __launch_bounds__(kBlock) void sgd_dense_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                           int64_t n4, int64_t n, float lr, float wd) {
+  float4* p4 = reinterpret_cast<float4*>(p);
+  float4* g4 = reinterpret_cast<float4*>(g);
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
-    float4 P = p[i], G = g[i];
+    float4 P = p4[i], G = g4[i];
     float* pp = reinterpret_cast<float*>(&P);
     float* gg = reinterpret_cast<float*>(&G);
 #pragma unroll
@@ -55,8 +71,17 @@ __global__ __launch_bounds__(kBlock) void sgd_dense_kernel(float4* __restrict__ 
       if (wd != 0.0f) grad = grad + wd * pp[k];
       pp[k] = pp[k] + (-lr) * grad;
     }
-    p[i] = P;
-    if (ZERO_GRAD) g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    p4[i] = P;
+    if (ZERO_GRAD) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t i = 4 * n4 + threadIdx.x;
+    if (i < n) {
+      float grad = g[i];
+      if (wd != 0.0f) grad = grad + wd * p[i];
+      p[i] = p[i] + (-lr) * grad;
+      if (ZERO_GRAD) g[i] = 0.0f;
+    }
   }
 }
 
@@ -69,19 +94,27 @@ using namespace yr;
 extern "C" int yr_adam_dense(float* p, float* g, float* m, float* v, int64_t n, double lr, double step_size,
                              double bc2_sqrt, double beta1, double beta2, double eps, double weight_decay,
                              int mode, int zero_grad, void* stream) {
-  if (n < 0 || (n & 3)) return YR_ERR_BADARG;
+  if (n < 0) return YR_ERR_BADARG;
   if (n == 0) return 0;
   if (!p || !g || !m || !v) return YR_ERR_BADARG;
-  if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return YR_ERR_BADARG;
   if (mode != YR_OPT_ADAM && mode != YR_OPT_ADAMW) return YR_ERR_UNSUPPORTED;
+  // vector body only when all four buffers are 16-byte aligned; otherwise all-scalar tail is
+  // impossible (tail <= 255 elements), so misaligned buffers are rejected
+  if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return YR_ERR_BADARG;
   const int64_t n4 = n / 4;
-  const int grid = grid_for(n4, kBlock);
+  const int grid = grid_for(n4 > 0 ? n4 : 1, kBlock);
   hipStream_t s = (hipStream_t)stream;
-#define YR_LAUNCH_ADAM(DEC, ZG)                                                                              \
-  hipLaunchKernelGGL((adam_dense_kernel<DEC, ZG>), dim3(grid), dim3(kBlock), 0, s, (float4*)p, (float4*)g,   \
-                     (float4*)m, (float4*)v, n4, (float)(1.0 - lr * weight_decay), (float)(-step_size),          \
-                     (float)bc2_sqrt, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,       \
-                     (float)weight_decay)
+  AdamScalars c;
+  c.decay_mul = (float)(1.0 - lr * weight_decay);
+  c.neg_step = (float)(-step_size);
+  c.bc2_sqrt = (float)bc2_sqrt;
+  c.one_m_b1 = (float)(1.0 - beta1);
+  c.beta2 = (float)beta2;
+  c.one_m_b2 = (float)(1.0 - beta2);
+  c.eps = (float)eps;
+  c.wd = (float)weight_decay;
+#define YR_LAUNCH_ADAM(DEC, ZG) \
+  hipLaunchKernelGGL((adam_dense_kernel<DEC, ZG>), dim3(grid), dim3(kBlock), 0, s, p, g, m, v, n4, n, c)
   if (mode == YR_OPT_ADAMW) {
     if (zero_grad) YR_LAUNCH_ADAM(true, true); else YR_LAUNCH_ADAM(true, false);
   } else {
@@ -93,17 +126,17 @@ extern "C" int yr_adam_dense(float* p, float* g, float* m, float* v, int64_t n, 
 
 extern "C" int yr_sgd_dense(float* p, float* g, int64_t n, double lr, double weight_decay, int zero_grad,
                             void* stream) {
-  if (n < 0 || (n & 3)) return YR_ERR_BADARG;
+  if (n < 0) return YR_ERR_BADARG;
   if (n == 0) return 0;
   if (!p || !g || !aligned16(p) || !aligned16(g)) return YR_ERR_BADARG;
   const int64_t n4 = n / 4;
-  const int grid = grid_for(n4, kBlock);
+  const int grid = grid_for(n4 > 0 ? n4 : 1, kBlock);
   hipStream_t s = (hipStream_t)stream;
   if (zero_grad)
-    hipLaunchKernelGGL((sgd_dense_kernel<true>), dim3(grid), dim3(kBlock), 0, s, (float4*)p, (float4*)g, n4,
-                       (float)lr, (float)weight_decay);
+    hipLaunchKernelGGL((sgd_dense_kernel<true>), dim3(grid), dim3(kBlock), 0, s, p, g, n4, n, (float)lr,
+                       (float)weight_decay);
   else
-    hipLaunchKernelGGL((sgd_dense_kernel<false>), dim3(grid), dim3(kBlock), 0, s, (float4*)p, (float4*)g, n4,
-                       (float)lr, (float)weight_decay);
+    hipLaunchKernelGGL((sgd_dense_kernel<false>), dim3(grid), dim3(kBlock), 0, s, p, g, n4, n, (float)lr,
+                       (float)weight_decay);
   return launch_status();
 }

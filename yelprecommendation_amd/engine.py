@@ -120,6 +120,68 @@ def loss_finalize(loss_partials, scale, loss_out=None, loss_accum=None):
     return loss_out
 
 
+MASK_VALUE = -3.40282e+38     # reference trainers/mf_trainer.py:167
+
+
+def topk_masked(scores, mask_ptr, mask_idx, k, mask_value=MASK_VALUE, out=None):
+    """Row-wise top-k of ``scores[R, N]`` with per-row masked columns (CSR) forced to
+    ``mask_value`` first (reference trainers/mf_trainer.py:163-178).  -> int64 [R, k]."""
+    lib = _lib.load()
+    if scores.dim() != 2 or scores.stride(1) != 1:
+        raise EngineError("scores must be [rows, cols] with unit column stride")
+    if not scores.is_cuda or scores.dtype != torch.float32:
+        raise EngineError("scores must be a float32 GPU tensor (no CPU fallback)")
+    R, N = scores.shape
+    if out is None:
+        out = torch.empty((R, k), dtype=torch.int64, device=scores.device)
+    if mask_ptr is not None and mask_ptr.numel() != R + 1:
+        raise EngineError("mask_ptr must have rows + 1 entries")
+    check(lib.yr_topk_masked(scores.data_ptr(), R, N, scores.stride(0) if R > 1 else N,
+                             _opt(mask_ptr, torch.int64, "mask_ptr"), _opt(mask_idx, torch.int64, "mask_idx"),
+                             float(mask_value), int(k), _dev(out, torch.int64, "out"), _stream()),
+          "yr_topk_masked")
+    return out
+
+
+def mf_recommend(U, I, users, mask_ptr, mask_idx, k, chunk_users=512):
+    """Top-k unmasked items for each user id in ``users`` (reference
+    trainers/mf_trainer.py:134-144 + :163-178, batched): full-catalogue scores
+    ``U[users] @ I^T`` with the per-user mask and the top-k selection on the device."""
+    nu_tab, ni, d = _table_dims(U, I)
+    n = users.numel()
+    out = torch.empty((n, k), dtype=torch.int64, device=U.device)
+    items = torch.arange(ni, dtype=torch.int64, device=U.device)
+    flag = new_error_flag(U.device)
+    for lo in range(0, n, chunk_users):
+        hi = min(lo + chunk_users, n)
+        uu = users[lo:hi]
+        scores = mf_score(U, I, uu.repeat_interleave(ni), items.repeat(hi - lo), err_flag=flag)
+        ptr = (mask_ptr[lo:hi + 1] - mask_ptr[lo]).contiguous()
+        topk_masked(scores.view(hi - lo, ni), ptr, mask_idx[int(mask_ptr[lo]):], k, out=out[lo:hi])
+    raise_on_flag(flag, "mf_recommend")
+    return out
+
+
+def bpr_loss_fwd(pos, neg, loss_partials):
+    """Partial sums of softplus(-(pos - neg))  (reference loss.py:25-27)."""
+    lib = _lib.load()
+    B = pos.numel()
+    if neg.numel() != B:
+        raise EngineError("pos and neg differ in length")
+    check(lib.yr_bpr_loss_fwd(_dev(pos, torch.float32, "pos"), _dev(neg, torch.float32, "neg"), B,
+                              _dev(loss_partials, torch.float32, "loss_partials"), _stream()), "yr_bpr_loss_fwd")
+
+
+def bpr_loss_bwd(pos, neg, gout, gpos, gneg):
+    """d mean(-logsigmoid(pos-neg)) / d pos, d neg, scaled by the scalar gout."""
+    lib = _lib.load()
+    B = pos.numel()
+    check(lib.yr_bpr_loss_bwd(_dev(pos, torch.float32, "pos"), _dev(neg, torch.float32, "neg"),
+                              _dev(gout, torch.float32, "gout"), 1.0 / B if B else 0.0, B,
+                              _dev(gpos, torch.float32, "gpos"), _dev(gneg, torch.float32, "gneg"), _stream()),
+          "yr_bpr_loss_bwd")
+
+
 def adam_scalars(step: int, lr: float, beta1: float, beta2: float):
     """Host doubles of torch's Adam step: (lr / (1 - b1^t), sqrt(1 - b2^t))."""
     return lr / (1.0 - beta1 ** step), (1.0 - beta2 ** step) ** 0.5

@@ -1,0 +1,134 @@
+"""BPR-MF trainer — drop-in for reference trainers/mf_trainer.py:22-178.
+
+Same constructor ``MFTrainer(cfg, num_items, num_users)`` and the same
+``run / train / validate / evaluate / _generate_top_k_recommendation`` contract:
+``train`` and ``validate`` return the SUM of per-batch mean losses, ``evaluate``
+returns ``(precision, recall, map, ndcg)@top_n``.
+
+Differences underneath (results equal to float rounding):
+* one fused HIP kernel per batch instead of 2 x forward + loss + backward
+  (mf_trainer.py:106-111); the optimizer step also clears the gradients;
+* the running loss stays on the device — one host sync per epoch, not per step
+  (mf_trainer.py:114 syncs every batch);
+* ``evaluate`` scores all eval users against the whole catalogue on the device with
+  the train-item mask and top-k fused in, instead of a Python loop of per-user
+  forward calls (mf_trainer.py:139-144).
+"""
+import numpy as np
+import torch
+
+from .. import engine
+from ..loss import BPRLoss
+from ..metric import ranking_metrics
+from ..models.mf import MatrixFactorization
+from ..utils import logger
+from .base_trainer import BaseTrainer
+
+
+def _lists_to_csr(lists):
+    ptr = np.zeros(len(lists) + 1, dtype=np.int64)
+    np.cumsum([len(l) for l in lists], out=ptr[1:])
+    idx = np.fromiter((x for l in lists for x in l), dtype=np.int64, count=int(ptr[-1]))
+    return ptr, idx
+
+
+class MFTrainer(BaseTrainer):
+    def __init__(self, cfg, num_items: int, num_users: int) -> None:
+        super().__init__(cfg)
+        self.num_items = num_items
+        self.num_users = num_users
+        self.model = MatrixFactorization(self.cfg, num_users, num_items).to(self.device)
+        self.optimizer = self._optimizer(self.cfg.optimizer, self.model, self.cfg.lr, self.cfg.weight_decay)
+        self.loss = self._loss()
+        self._loss_accum = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self._eval_cache = {}
+
+    def _loss(self):
+        return BPRLoss()
+
+    def run(self, train_dataloader, valid_dataloader, valid_eval_data):
+        # reference mf_trainer.py:34-97
+        logger.info("[Trainer] run...")
+        best = (1e+6, .0, .0, .0, .0)
+        endurance = 0
+        for epoch in range(self.cfg.epochs):
+            train_loss = self.train(train_dataloader)
+            valid_loss = self.validate(valid_dataloader)
+            current = (valid_loss,) + tuple(self.evaluate(valid_eval_data, 'valid'))
+            self._log_epoch(epoch, train_loss, *current)
+            if self._is_surpass_best_metric(current=current, best=best):
+                logger.info("[Trainer] update best model...")
+                best = current
+                endurance = 0
+                torch.save(self.model.state_dict(), f'{self.cfg.model_dir}/best_model.pt')
+            else:
+                endurance += 1
+                if endurance > self.cfg.patience:
+                    logger.info("[Trainer] ealry stopping...")
+                    break
+
+    def _batch(self, data):
+        dev = self.device
+        return (data['user_id'].to(dev, non_blocking=True), data['pos_item'].to(dev, non_blocking=True),
+                data['neg_item'].to(dev, non_blocking=True))
+
+    def train(self, train_dataloader) -> float:
+        # reference mf_trainer.py:100-116
+        self.model.train()
+        self._loss_accum.zero_()
+        for data in train_dataloader:
+            user_id, pos_item, neg_item = self._batch(data)
+            self.model.bpr_loss_backward(user_id, pos_item, neg_item, loss_accum=self._loss_accum)
+            self.optimizer.step(zero_grad=True)
+        self.model.check_indices()
+        return float(self._loss_accum.item())
+
+    def validate(self, valid_dataloader) -> float:
+        # reference mf_trainer.py:118-132
+        self.model.eval()
+        self._loss_accum.zero_()
+        for data in valid_dataloader:
+            user_id, pos_item, neg_item = self._batch(data)
+            self.model.bpr_loss_backward(user_id, pos_item, neg_item, loss_accum=self._loss_accum, backward=False)
+        self.model.check_indices()
+        return float(self._loss_accum.item())
+
+    # -- evaluation -------------------------------------------------------------------------
+    def _eval_arrays(self, eval_data):
+        """eval_data: DataFrame indexed by user_id with list columns 'pos_items' and
+        'mask_items' (reference mf_data_pipeline.py:49-50).  Cached CSR + device copies."""
+        key = id(eval_data)
+        if key not in self._eval_cache:
+            users = np.asarray(eval_data.index.values, dtype=np.int64)
+            pos = [list(x) for x in eval_data['pos_items']]
+            mask_ptr, mask_idx = _lists_to_csr([list(x) for x in eval_data['mask_items']])
+            dev = self.device
+            self._eval_cache[key] = (eval_data, pos, torch.from_numpy(users).to(dev),
+                                     torch.from_numpy(mask_ptr).to(dev), torch.from_numpy(mask_idx).to(dev))
+        return self._eval_cache[key][1:]
+
+    def recommend(self, users, mask_ptr, mask_idx):
+        """Top-``top_n`` item ids per user, masked items excluded ([n_users, top_n] int64, device)."""
+        return engine.mf_recommend(self.model.user_embedding.weight.detach(),
+                                   self.model.item_embedding.weight.detach(),
+                                   users, mask_ptr, mask_idx, self.cfg.top_n)
+
+    def evaluate(self, eval_data, mode='valid') -> tuple:
+        # reference mf_trainer.py:134-161
+        self.model.eval()
+        actual, users, mask_ptr, mask_idx = self._eval_arrays(eval_data)
+        predicted = self.recommend(users, mask_ptr, mask_idx).cpu().numpy()
+        p, r, m, n = ranking_metrics(actual, predicted.tolist(), self.cfg.top_n)
+        if mode == 'test':
+            logger.info(f"[Trainer] Test > precision@{self.cfg.top_n} : {p:.4f} / Recall@{self.cfg.top_n}: {r:.4f} / "
+                        f"MAP@{self.cfg.top_n}: {m:.4f} / NDCG@{self.cfg.top_n}: {n:.4f}")
+        return (p, r, m, n)
+
+    def _generate_top_k_recommendation(self, pred, mask_items):
+        """reference mf_trainer.py:163-178 for ONE user's score vector (kept for callers
+        that score users one at a time); the batched path is :meth:`recommend`."""
+        dev = pred.device
+        mask = torch.as_tensor(np.asarray(mask_items, dtype=np.int64), device=dev)
+        ptr = torch.tensor([0, mask.numel()], dtype=torch.int64, device=dev)
+        top = engine.topk_masked(pred.detach().reshape(1, -1).contiguous(), ptr, mask, self.cfg.top_n)
+        return top[0].cpu().numpy()
