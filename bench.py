@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the BPR-MF hot path on MI355X (BASELINE.json metric:
+"BPR triplets/sec @ dim64 (1/2/4/8 GPU)").
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path over one batch of synthetic Yelp2018-shaped triplets:
+gather + BPR scoring + loss + gradient of both embedding tables + dense Adam on every row
+(reference trainers/mf_trainer.py:104-112), inputs already resident in HBM.  At N > 1 the
+interaction matrix is sharded by user (one rank per GPU, its users' rows + Adam state local,
+the item table replicated) with one RCCL all-reduce on the item-embedding gradient per step;
+per-GPU batch is fixed ("weak" scaling) and `value` is the whole-job triplets/s.
+
+Rank 0 prints ONE JSON line (contract in the task statement) that also carries
+  "roofline":     the dominant kernel's achieved algorithmic bytes/s vs the 8 TB/s HBM peak,
+                  its launch durations measured with HIP events inside the timed region;
+  "cpu_baseline": the reference's CPU op sequence (oracle/mf_torch_cpu.py) timed on this
+                  host on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+DIM = 64
+DEFAULT_BATCH = 1 << 20        # triplets per GPU per step (~ one epoch of Yelp2018 train rows)
+
+
+def algorithmic_bytes_per_triplet(dim):
+    """3 int64 ids + 3 gathered rows + 3 gradient rows, counted once."""
+    return 24 + 24 * dim
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="triplets per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-baseline work")
+    ap.add_argument("--sweep", action="store_true", help="also time other batch sizes (N=1 only)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node "
+                             f"{args.gpus} --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
+
+    from yelprecommendation_amd.bpr_step import BPRMFStep
+    from yelprecommendation_amd.data.synthetic import YELP2018_ITEMS, YELP2018_USERS, make_interactions_torch
+    from yelprecommendation_amd.data.triplets import TripletSampler, split_train_rows
+    from yelprecommendation_amd.user_shard import UserShard
+
+    # ---- synthetic Yelp2018-shaped input (identical on every rank: same seed) ------------------
+    t0 = time.time()
+    gen = torch.Generator(device=dev).manual_seed(4321)
+    iu, ii = make_interactions_torch(YELP2018_USERS, YELP2018_ITEMS, 47.0, seed=1234, device=dev)
+    num_users, num_items, nnz = YELP2018_USERS, YELP2018_ITEMS, iu.numel()
+    label = split_train_rows(iu, ii, generator=gen)
+    tr = label == 0
+    shard = UserShard(num_users, world, rank)
+    mine = tr & (iu >= shard.lo) & (iu < shard.hi)
+    sampler = TripletSampler(iu[mine] - shard.lo, ii[mine], shard.size, num_items, seed=99 + rank)
+    n_train_local = len(sampler)
+    n_train_global = int(tr.sum())
+    B = args.batch
+    n_pool = max(1, min(4, args.steps + args.warmup))
+    su, sp, sn = sampler.stream(B * n_pool)
+    pool = [(su[k * B:(k + 1) * B].contiguous(), sp[k * B:(k + 1) * B].contiguous(),
+             sn[k * B:(k + 1) * B].contiguous()) for k in range(n_pool)]
+    del su, sp, sn, iu, ii, label, tr, mine
+    data_s = time.time() - t0
+
+    # ---- tables: xavier-uniform like models/mf.py:15-18; user rows sharded, items replicated ---
+    g2 = torch.Generator(device=dev).manual_seed(7)
+    bu = (6.0 / (num_users + DIM)) ** 0.5
+    bi = (6.0 / (num_items + DIM)) ** 0.5
+    U = ((torch.rand(num_users, DIM, generator=g2, device=dev) * 2 - 1) * bu)[shard.lo:shard.hi].contiguous()
+    I = (torch.rand(num_items, DIM, generator=g2, device=dev) * 2 - 1) * bi
+    step = BPRMFStep(U, I, lr=1e-4, optimizer="adam", world_size=world,
+                     process_group=(dist.group.WORLD if dist else None), time_kernels=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(steps, timed):
+        for k in range(steps):
+            u, p, n = pool[k % n_pool]
+            step.step(u, p, n, record=timed)
+
+    run(args.warmup, False)
+    barrier()
+    step.reset_timers()
+    t0 = time.perf_counter()
+    run(args.steps, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    step.check()
+    value = world * B * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (HIP events inside the timed region) --------------------
+    kt = step.kernel_times()                     # {name: (avg_us, launches, algorithmic bytes per launch)}
+    dom = max(kt, key=lambda k: kt[k][0] * kt[k][1])
+    avg_us, launches, alg_bytes = kt[dom]
+    achieved = alg_bytes / (avg_us * 1e-6) / 1e9
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_kernel_us": round(avg_us, 2), "launches": launches,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "kernels_us": {k: round(v[0], 2) for k, v in kt.items()}}
+
+    out = {
+        "metric": "BPR triplets/sec @ dim64", "value": round(value, 1), "unit": "triplets/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BPR-MF dim=64 train step (gather+score+loss+grad+dense Adam), "
+                               "synthetic Yelp2018 shape, user-sharded" if world > 1 else
+                               "BPR-MF dim=64 train step (gather+score+loss+grad+dense Adam), synthetic Yelp2018 shape",
+                   "users": num_users, "items": num_items, "interactions": nnz,
+                   "train_triplets_per_epoch": n_train_global, "batch_per_gpu": B, "global_batch": B * world,
+                   "optimizer": "adam(dense)", "parallelism": f"user-shard x{world}" if world > 1 else "single",
+                   "step_impl": step.impl, "data_gen_s": round(data_s, 1)},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and args.sweep:
+        sweep = {}
+        for b in (4096, 65536, 262144):
+            uu, pp, nn = (t[:b].contiguous() for t in pool[0])
+            for _ in range(5):
+                step.step(uu, pp, nn)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(50):
+                step.step(uu, pp, nn)
+            torch.cuda.synchronize()
+            sweep[str(b)] = round(b * 50 / (time.perf_counter() - t1), 1)
+        out["batch_sweep_triplets_per_s"] = sweep
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.mf_torch_cpu import time_steps      # CPU baseline leg only (never the product path)
+        cpu_b = min(B, 1 << 20)
+        cpu_batches = [tuple(t[:cpu_b].cpu() for t in pool[k]) for k in range(min(2, n_pool))]
+        tps, csteps, csec = time_steps(num_users, num_items, DIM, cpu_batches, budget_s=args.cpu_budget)
+        out["cpu_baseline"] = {"value": round(tps, 1), "unit": "triplets/s", "cores": torch.get_num_threads(),
+                               "kind": "port",
+                               "sample": f"{csteps} steps of batch {cpu_b} (same tables/shape/stream), {csec:.1f} s, "
+                                         "torch-CPU op sequence of mf_trainer.py:104-114 with dense Adam"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

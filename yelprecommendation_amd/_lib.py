@@ -48,6 +48,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64 (same SONAME as /opt/rocm's).  It must be the first HIP
+    # runtime mapped into the process so that this library and torch share ONE runtime (and
+    # one set of streams / device pointers); loading ours first leaves torch with no device.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise EngineError(
             f"HIP engine library not found at {LIB_PATH}. Build it with "

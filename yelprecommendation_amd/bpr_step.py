@@ -1,0 +1,95 @@
+"""One BPR-MF optimisation step as a short, fixed sequence of HIP launches.
+
+This is the engine object behind ``MFTrainer.train`` and ``bench.py``: it owns the dense
+gradient buffers and the Adam state next to the two tables and enqueues, per batch,
+  fused gather + BPR score + loss + scatter-add gradient      (csrc/bpr_mf.hip)
+  [N > 1 GPUs: RCCL all-reduce(SUM) of the item gradient, overlapped with the user update]
+  dense Adam on the user rows, dense Adam on the item rows (clearing the gradients)
+equal — to float rounding — to the reference's per-batch sequence
+(trainers/mf_trainer.py:104-112 with torch.optim.Adam, base_trainer.py:34-36).
+The running loss stays on the device.
+"""
+import torch
+
+from . import engine
+
+
+class BPRMFStep:
+    impl = "v1: fused gather/score/loss + float-atomic scatter-add, dense Adam"
+
+    def __init__(self, U, I, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, optimizer="adam",
+                 world_size=1, process_group=None, time_kernels=False):
+        if optimizer.lower() not in ("adam", "adamw"):
+            raise NotImplementedError(f"BPRMFStep: optimizer {optimizer}")
+        self.U, self.I = U, I
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.decoupled = optimizer.lower() == "adamw"
+        self.world_size, self.pg = world_size, process_group
+        dev = U.device
+        self.gU, self.gI = torch.zeros_like(U), torch.zeros_like(I)
+        self.mU, self.vU = torch.zeros_like(U), torch.zeros_like(U)
+        self.mI, self.vI = torch.zeros_like(I), torch.zeros_like(I)
+        self.t = 0
+        self.partials = torch.zeros(engine.LOSS_PARTIALS, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.loss_accum = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.flag = engine.new_error_flag(dev)
+        self.time_kernels = time_kernels
+        self._ev = {}
+        self._bytes = {}
+
+    # -- timing of individual kernels with events on the launch stream ------------------------
+    def reset_timers(self):
+        self._ev = {}
+
+    def _timed(self, name, alg_bytes, record, fn):
+        if not (record and self.time_kernels):
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self._ev.setdefault(name, []).append((a, b))
+        self._bytes[name] = alg_bytes
+
+    def kernel_times(self):
+        torch.cuda.synchronize()
+        return {k: (sum(a.elapsed_time(b) for a, b in v) * 1e3 / len(v), len(v), self._bytes[k])
+                for k, v in self._ev.items()}
+
+    # -- the step -----------------------------------------------------------------------------
+    def step(self, u, p, n, record=False):
+        B = u.numel()
+        D = self.U.shape[1]
+        inv = 1.0 / (B * self.world_size) if B else 0.0
+        self._timed("bpr_fwd_bwd", B * (24 + 24 * D), record, lambda: engine.bpr_mf_fwd_bwd(
+            self.U, self.I, u, p, n, self.gU, self.gI, self.partials, inv_batch=inv, err_flag=self.flag))
+        work = None
+        if self.world_size > 1:
+            import torch.distributed as dist
+            work = dist.all_reduce(self.gI, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        engine.loss_finalize(self.partials, inv, self.loss, self.loss_accum)
+        self.t += 1
+        nU, nI = self.U.numel(), self.I.numel()
+        self._timed("adam_dense_user", 8 * 4 * nU, record, lambda: engine.adam_dense(
+            self.U, self.gU, self.mU, self.vU, self.t, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+            decoupled=self.decoupled, zero_grad=True))
+        if work is not None:
+            work.wait()
+        self._timed("adam_dense_item", 8 * 4 * nI, record, lambda: engine.adam_dense(
+            self.I, self.gI, self.mI, self.vI, self.t, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+            decoupled=self.decoupled, zero_grad=True))
+
+    def epoch_loss(self, reset=True):
+        """Sum of per-batch mean losses since the last reset (one host sync).  At N > 1 the
+        per-rank partial means (already scaled by 1/B_global) are summed across ranks."""
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.loss_accum, op=dist.ReduceOp.SUM, group=self.pg)
+        v = float(self.loss_accum.item())
+        if reset:
+            self.loss_accum.zero_()
+        return v
+
+    def check(self):
+        engine.raise_on_flag(self.flag, "BPRMFStep")

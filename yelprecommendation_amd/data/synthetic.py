@@ -104,3 +104,48 @@ def make_frame(*args, **kwargs):
     import pandas as pd
     u, i, r = make_interactions(*args, **kwargs)
     return pd.DataFrame({"user_id": u, "business_id": i, "rating": r})
+
+
+def make_interactions_torch(num_users: int = YELP2018_USERS, num_items: int = YELP2018_ITEMS,
+                            mean_items: float = 47.0, seed: int = 1234, latent_dim: int = 8,
+                            device="cpu", chunk: int = 2048, min_item_degree: int = 5):
+    """Same generative model as :func:`make_interactions`, on torch tensors (any device),
+    for the benchmark's full-size input (seconds on the GPU instead of ~1 min of NumPy).
+    Not bit-identical to the NumPy generator (different RNG); same distribution/shape.
+    Returns ``(user_id, business_id)`` int64 tensors sorted by (user, item) on ``device``;
+    every user has >= 5 items and every item >= ``min_item_degree`` users.
+    """
+    import torch
+    g = torch.Generator(device=device).manual_seed(seed)
+    P = torch.randn(num_users, latent_dim, generator=g, device=device)
+    Q = torch.randn(num_items, latent_dim, generator=g, device=device)
+    # Zipf(1.5) popularity by inverse-CDF on the Pareto tail, floored and capped at 50
+    uq = torch.rand(num_items, generator=g, device=device).clamp_(1e-7, 1.0)
+    pop = torch.floor(uq.pow(-1.0 / 0.5)).clamp_(1.0, 50.0)
+    log_pop = pop.log()
+    n_per_user = torch.poisson(torch.full((num_users,), float(mean_items), device=device), generator=g)
+    n_per_user = n_per_user.clamp_(5, num_items).long()
+    users, items = [], []
+    for lo in range(0, num_users, chunk):
+        hi = min(lo + chunk, num_users)
+        logits = 1.5 * (P[lo:hi] @ Q.T) + log_pop[None, :]
+        u = torch.rand(logits.shape, generator=g, device=device).clamp_(1e-20, 1.0 - 1e-7)
+        logits -= torch.log(-torch.log(u))
+        kmax = int(n_per_user[lo:hi].max())
+        top = torch.topk(logits, kmax, dim=1).indices                       # Gumbel top-k
+        keep = torch.arange(kmax, device=device)[None, :] < n_per_user[lo:hi, None]
+        rows = torch.arange(lo, hi, device=device)[:, None].expand(-1, kmax)
+        users.append(rows[keep])
+        items.append(top[keep])
+    user_id = torch.cat(users)
+    item_id = torch.cat(items)
+    if min_item_degree > 0:
+        deg = torch.bincount(item_id, minlength=num_items)
+        need = (min_item_degree - deg).clamp_(min=0)
+        if int(need.sum()) > 0:
+            add_i = torch.repeat_interleave(torch.arange(num_items, device=device), need)
+            add_u = torch.randint(0, num_users, (add_i.numel(),), generator=g, device=device)
+            user_id = torch.cat([user_id, add_u])
+            item_id = torch.cat([item_id, add_i])
+    key = torch.unique(user_id * num_items + item_id)                       # sorted, de-duplicated
+    return torch.div(key, num_items, rounding_mode="floor"), key % num_items
