@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 1
+#define YR_ENGINE_VERSION 4
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -94,6 +94,41 @@ int yr_bpr_mf_fwd_bwd(const float *U, const float *I,
                       int64_t B, int D, int64_t num_users, int64_t num_items,
                       float inv_batch, float *gradU, float *gradI,
                       float *loss_partials, int32_t *err_flag, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * One whole BPR-MF optimisation step, pull-based (no float atomics, no gradient buffers):
+ *   reference trainers/mf_trainer.py:106-112 = 2 x forward + BPRLoss + loss.backward()
+ *   + torch.optim.Adam/AdamW.step() (trainers/base_trainer.py:34-38), dense semantics
+ *   (every row of both tables is updated, rows without contributions with grad = 0).
+ * Sequence enqueued on `stream`: two-level counting sort of the batch by user and by item
+ * (level 1: buckets of 64 rows, LDS histograms + one global integer atomic per workgroup and
+ * bucket; level 2: LDS counting sort inside each bucket), a fused pass over the user rows
+ * (scores, loss, user gradient in registers, Adam -> U_new; per-occurrence coefficients for
+ * the item pass), a fused pass over the item rows (item gradient from the OLD user rows,
+ * Adam in place).  See csrc/bpr_pull.hip.  Limits: num_users, num_items < 2^24.
+ *
+ *   U_old  [num_users, D]  read;  U_new [num_users, D] written (must not alias U_old:
+ *          the caller ping-pongs the two buffers between steps);
+ *   I      [num_items, D]  updated in place;  mU,vU,mI,vI: Adam state, updated in place;
+ *   gradI_out: NULL for one GPU.  If non-NULL the item pass writes the dense item gradient
+ *          [num_items, D] there INSTEAD of applying Adam (mI/vI/I untouched): the caller
+ *          all-reduces it across ranks and applies yr_adam_dense (user-sharded multi-GPU);
+ *   inv_batch: 1 / (global batch size); loss_partials as for yr_bpr_mf_fwd_bwd;
+ *   lr..weight_decay, step_size, bc2_sqrt, mode: as for yr_adam_dense;
+ *   heavy_threshold: rows with more contributions than this are summed by a whole
+ *          1024-thread workgroup instead of one wave (<= 0: default 256);
+ *   workspace: >= yr_bpr_mf_pull_workspace_bytes(B, num_users, num_items) bytes, 16-byte
+ *          aligned, contents irrelevant on entry.
+ * ------------------------------------------------------------------------- */
+int64_t yr_bpr_mf_pull_workspace_bytes(int64_t max_batch, int64_t num_users, int64_t num_items);
+int yr_bpr_mf_pull_step(const float *U_old, float *U_new, float *I,
+                        float *mU, float *vU, float *mI, float *vI, float *gradI_out,
+                        const int64_t *user, const int64_t *pos, const int64_t *neg,
+                        int64_t B, int D, int64_t num_users, int64_t num_items, float inv_batch,
+                        double lr, double step_size, double bc2_sqrt,
+                        double beta1, double beta2, double eps, double weight_decay, int mode,
+                        int heavy_threshold, void *workspace, int64_t workspace_bytes,
+                        float *loss_partials, int32_t *err_flag, void *stream);
 
 /* loss_out[0] = scale * sum(loss_partials);  if loss_accum: loss_accum[0] += same.
  * (`train_loss += loss.item()` of mf_trainer.py:114 without the per-step host sync;

@@ -1,0 +1,113 @@
+"""GPU parity of the pull-based BPR-MF step (csrc/bpr_pull.hip, through the C ABI) against the
+NumPy oracle: loss, both tables and the Adam state after several steps, for every supported
+width, with light-only, heavy-only and mixed row handling, uniform and popularity-skewed batches,
+empty and ragged batches, several partition tiles."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bpr_mf as obpr
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(rs, nu, ni, d):
+    U = (rs.standard_normal((nu, d)) * 0.2).astype(np.float32)
+    I = (rs.standard_normal((ni, d)) * 0.2).astype(np.float32)
+    return U, I
+
+
+def _batch(rs, nu, ni, B, skew):
+    u = rs.randint(0, nu, size=B)
+    if skew:   # popularity-skewed positives => a few very heavy item rows
+        p = np.minimum((rs.pareto(1.2, size=B) * 3).astype(np.int64), ni - 1)
+    else:
+        p = rs.randint(0, ni, size=B)
+    n = rs.randint(0, ni, size=B)
+    return u.astype(np.int64), p.astype(np.int64), n.astype(np.int64)
+
+
+@pytest.mark.parametrize("d", [16, 32, 64, 128])
+@pytest.mark.parametrize("B,heavy_t,skew", [(1, 0, False), (257, 0, False), (3000, 0, True), (3000, 4, True),
+                                            (3000, 1, False), (9000, 64, True), (20000, 0, False)])
+def test_pull_step_matches_oracle(device, d, B, heavy_t, skew):
+    from yelprecommendation_amd.bpr_step import BPRMFStep
+    rs = np.random.RandomState(7 * d + B + heavy_t)
+    nu, ni = 211, 307
+    U, I = _setup(rs, nu, ni, d)
+    ref = obpr.MFState(U, I, "adam", lr=5e-3)
+    step = BPRMFStep(torch.from_numpy(U).to(device), torch.from_numpy(I).to(device), lr=5e-3,
+                     impl="pull", heavy_threshold=heavy_t)
+    total = 0.0
+    for k in range(4):
+        u, p, n = _batch(rs, nu, ni, B if k != 2 else max(1, B // 3), skew)   # ragged: step 2 is shorter
+        total += float(ref.train_step(u, p, n))
+        step.step(*(torch.from_numpy(a).to(device) for a in (u, p, n)))
+    got = step.epoch_loss()
+    step.check()
+    np.testing.assert_allclose(got, total, rtol=2e-5)
+    # Adam's m/sqrt(v) amplifies gradient rounding where a gradient nearly cancels: an element
+    # may differ by a small fraction of one step (lr = 5e-3), hence atol = 2e-3 * lr
+    np.testing.assert_allclose(step.U.cpu().numpy(), ref.U, rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(step.I.cpu().numpy(), ref.I, rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(step.mU.cpu().numpy(), ref.opt.m[0], rtol=1e-3, atol=1e-8)
+    np.testing.assert_allclose(step.vI.cpu().numpy(), ref.opt.v[1], rtol=1e-3, atol=1e-11)
+
+
+def test_pull_step_empty_batch_still_decays_state(device):
+    """Dense-Adam semantics: a step with no triplets still moves every row (m/v decay)."""
+    from yelprecommendation_amd.bpr_step import BPRMFStep
+    rs = np.random.RandomState(3)
+    U, I = _setup(rs, 50, 60, 64)
+    ref = obpr.MFState(U, I, "adam", lr=1e-2)
+    step = BPRMFStep(torch.from_numpy(U).to(device), torch.from_numpy(I).to(device), lr=1e-2, impl="pull")
+    u, p, n = _batch(rs, 50, 60, 500, False)
+    ref.train_step(u, p, n)
+    step.step(*(torch.from_numpy(a).to(device) for a in (u, p, n)))
+    e = np.zeros(0, np.int64)
+    gU, gI = np.zeros_like(ref.U), np.zeros_like(ref.I)
+    ref.opt.step([gU, gI])                                   # zero gradient, state still advances
+    step.step(*(torch.from_numpy(e).to(device) for _ in range(3)))
+    np.testing.assert_allclose(step.U.cpu().numpy(), ref.U, rtol=1e-3, atol=2e-6)
+    np.testing.assert_allclose(step.I.cpu().numpy(), ref.I, rtol=1e-3, atol=2e-6)
+
+
+def test_pull_step_flags_bad_indices(device):
+    from yelprecommendation_amd.bpr_step import BPRMFStep
+    rs = np.random.RandomState(4)
+    U, I = _setup(rs, 20, 30, 32)
+    step = BPRMFStep(torch.from_numpy(U).to(device), torch.from_numpy(I).to(device), impl="pull")
+    u = torch.tensor([0, 1, 20, 3], dtype=torch.int64, device=device)
+    p = torch.tensor([0, 30, 2, 3], dtype=torch.int64, device=device)
+    n = torch.tensor([5, 6, 7, -2], dtype=torch.int64, device=device)
+    step.step(u, p, n)
+    with pytest.raises(IndexError):
+        step.check()
+    # the single valid triplet (0, 0, 5) was applied with inv_batch = 1/4
+    ref = obpr.MFState(U, I, "adam", lr=1e-4)
+    loss, gU, gI = obpr.loss_and_grads(ref.U, ref.I, np.array([0]), np.array([0]), np.array([5]))
+    ref.opt.step([gU * 0.25, gI * 0.25])
+    np.testing.assert_allclose(step.I.cpu().numpy(), ref.I, rtol=1e-3, atol=2e-6)
+
+
+def test_pull_equals_atomic_at_yelp_shape(device):
+    """Size-independent property at BASELINE's full table size: the two implementations of the
+    step agree (same loss to 1e-5, same tables to rounding) on a popularity-skewed batch."""
+    from yelprecommendation_amd.bpr_step import BPRMFStep
+    g = torch.Generator(device=device).manual_seed(1)
+    nu, ni, d, B = 31668, 38048, 64, 1 << 18
+    U = (torch.rand(nu, d, generator=g, device=device) - 0.5) * 0.05
+    I = (torch.rand(ni, d, generator=g, device=device) - 0.5) * 0.05
+    a = BPRMFStep(U.clone(), I.clone(), lr=1e-3, impl="pull")
+    b = BPRMFStep(U.clone(), I.clone(), lr=1e-3, impl="atomic")
+    for k in range(3):
+        u = torch.randint(0, nu, (B,), generator=g, device=device)
+        p = (torch.rand(B, generator=g, device=device).pow(3) * ni).long().clamp_(max=ni - 1)
+        n = torch.randint(0, ni, (B,), generator=g, device=device)
+        a.step(u, p, n)
+        b.step(u, p, n)
+    la, lb = a.epoch_loss(), b.epoch_loss()
+    a.check(); b.check()
+    assert abs(la - lb) <= 1e-5 * abs(lb)
+    torch.testing.assert_close(a.U, b.U, rtol=1e-3, atol=1e-6)
+    torch.testing.assert_close(a.I, b.I, rtol=1e-3, atol=1e-6)

@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
-ENGINE_VERSION = 1
+ENGINE_VERSION = 4
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -28,6 +28,9 @@ SIGNATURES = {
     "yr_mf_score": [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _p],
     "yr_mf_score_backward": [_p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _p, _p],
     "yr_bpr_mf_fwd_bwd": [_p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _f, _p, _p, _p, _p, _p],
+    "yr_bpr_mf_pull_workspace_bytes": [_i64, _i64, _i64],
+    "yr_bpr_mf_pull_step": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _f,
+                            _d, _d, _d, _d, _d, _d, _d, _int, _int, _p, _i64, _p, _p, _p],
     "yr_loss_finalize": [_p, _f, _p, _p, _p],
     "yr_topk_masked": [_p, _i64, _i64, _i64, _p, _p, _f, _int, _p, _p],
     "yr_bpr_loss_fwd": [_p, _p, _i64, _p, _p],
@@ -67,7 +70,8 @@ def load():
         except AttributeError as e:
             raise EngineError(f"{LIB_PATH} does not export {name}") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "yr_engine_arch" else C.c_int
+        fn.restype = {"yr_engine_arch": C.c_char_p,
+                      "yr_bpr_mf_pull_workspace_bytes": C.c_int64}.get(name, C.c_int)
     v = lib.yr_engine_version()
     if v != ENGINE_VERSION:
         raise EngineError(f"engine ABI version {v} != expected {ENGINE_VERSION}; rebuild the library")

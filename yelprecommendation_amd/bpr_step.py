@@ -8,25 +8,49 @@ gradient buffers and the Adam state next to the two tables and enqueues, per bat
 equal — to float rounding — to the reference's per-batch sequence
 (trainers/mf_trainer.py:104-112 with torch.optim.Adam, base_trainer.py:34-36).
 The running loss stays on the device.
+
+Two implementations of the same step:
+  impl="pull"   (default) csrc/bpr_pull.hip: two-level counting sort of the batch by user and
+                by item, then one fused pass per table in which each row pulls its contributions
+                into registers and applies Adam — no float atomics, no gradient buffers.  The user table is
+                double-buffered; ``self.U`` is always the current one.
+  impl="atomic" csrc/bpr_mf.hip + csrc/optim.hip: scatter-add with float atomics into dense
+                gradient buffers, then two dense Adam launches.
 """
 import torch
 
 from . import engine
 
 
-class BPRMFStep:
-    impl = "v1: fused gather/score/loss + float-atomic scatter-add, dense Adam"
+IMPL_NAMES = {
+    "pull": "pull: 2-level counting sort + fused per-row gather/score/loss/grad/Adam (no float atomics)",
+    "atomic": "atomic: fused gather/score/loss + float-atomic scatter-add, dense Adam",
+}
 
+
+class BPRMFStep:
     def __init__(self, U, I, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, optimizer="adam",
-                 world_size=1, process_group=None, time_kernels=False):
+                 world_size=1, process_group=None, time_kernels=False, impl="pull", max_batch=0,
+                 heavy_threshold=0):
         if optimizer.lower() not in ("adam", "adamw"):
             raise NotImplementedError(f"BPRMFStep: optimizer {optimizer}")
+        if impl not in IMPL_NAMES:
+            raise ValueError(f"impl must be one of {list(IMPL_NAMES)}")
+        self.impl_key, self.impl = impl, IMPL_NAMES[impl]
+        self.heavy_threshold = heavy_threshold
         self.U, self.I = U, I
+        self._U_alt = torch.empty_like(U) if impl == "pull" else None
+        self._ws, self._ws_batch = None, 0
+        if impl == "pull" and max_batch:
+            self._workspace(max_batch)
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.decoupled = optimizer.lower() == "adamw"
         self.world_size, self.pg = world_size, process_group
         dev = U.device
-        self.gU, self.gI = torch.zeros_like(U), torch.zeros_like(I)
+        need_gU = impl == "atomic"
+        need_gI = impl == "atomic" or world_size > 1
+        self.gU = torch.zeros_like(U) if need_gU else None
+        self.gI = torch.zeros_like(I) if need_gI else None
         self.mU, self.vU = torch.zeros_like(U), torch.zeros_like(U)
         self.mI, self.vI = torch.zeros_like(I), torch.zeros_like(I)
         self.t = 0
@@ -57,8 +81,43 @@ class BPRMFStep:
         return {k: (sum(a.elapsed_time(b) for a, b in v) * 1e3 / len(v), len(v), self._bytes[k])
                 for k, v in self._ev.items()}
 
+    def _workspace(self, batch):
+        if self._ws is None or batch > self._ws_batch:
+            self._ws = engine.bpr_mf_pull_workspace(batch, self.U.shape[0], self.I.shape[0], self.U.device)
+            self._ws_batch = batch
+        return self._ws
+
     # -- the step -----------------------------------------------------------------------------
     def step(self, u, p, n, record=False):
+        if self.impl_key == "pull":
+            return self._step_pull(u, p, n, record)
+        return self._step_atomic(u, p, n, record)
+
+    def _step_pull(self, u, p, n, record):
+        B = u.numel()
+        D = self.U.shape[1]
+        inv = 1.0 / (B * self.world_size) if B else 0.0
+        self.t += 1
+        ws = self._workspace(B)
+        multi = self.world_size > 1
+        nU, nI = self.U.numel(), self.I.numel()
+        # algorithmic bytes of the launch group: the per-triplet figure of SURVEY §8d plus the
+        # dense Adam pass it absorbs (read p,m,v + write p,m,v on every row of both tables)
+        alg = B * (24 + 24 * D) + 6 * 4 * (nU + (0 if multi else nI))
+        self._timed("bpr_pull_step", alg, record, lambda: engine.bpr_mf_pull_step(
+            self.U, self._U_alt, self.I, self.mU, self.vU, self.mI, self.vI, u, p, n, self.t, self.lr,
+            self.partials, ws, self.betas[0], self.betas[1], self.eps, self.wd, self.decoupled, inv_batch=inv,
+            gradI_out=self.gI if multi else None, heavy_threshold=self.heavy_threshold, err_flag=self.flag))
+        self.U, self._U_alt = self._U_alt, self.U
+        if multi:
+            import torch.distributed as dist
+            dist.all_reduce(self.gI, op=dist.ReduceOp.SUM, group=self.pg)
+            self._timed("adam_dense_item", 7 * 4 * nI, record, lambda: engine.adam_dense(
+                self.I, self.gI, self.mI, self.vI, self.t, self.lr, self.betas[0], self.betas[1], self.eps,
+                self.wd, decoupled=self.decoupled, zero_grad=False))
+        engine.loss_finalize(self.partials, inv, self.loss, self.loss_accum)
+
+    def _step_atomic(self, u, p, n, record):
         B = u.numel()
         D = self.U.shape[1]
         inv = 1.0 / (B * self.world_size) if B else 0.0

@@ -109,6 +109,49 @@ def bpr_mf_fwd_bwd(U, I, user, pos, neg, gradU, gradI, loss_partials, inv_batch=
                                 _opt(err_flag, torch.int32, "err_flag"), _stream()), "yr_bpr_mf_fwd_bwd")
 
 
+def bpr_mf_pull_workspace(max_batch, num_users, num_items, device):
+    """Scratch buffer for :func:`bpr_mf_pull_step` (uint8 tensor, 256-byte aligned by torch)."""
+    lib = _lib.load()
+    n = lib.yr_bpr_mf_pull_workspace_bytes(int(max_batch), int(num_users), int(num_items))
+    if n < 0:
+        check(int(n), "yr_bpr_mf_pull_workspace_bytes")
+    return torch.empty(int(n), dtype=torch.uint8, device=device)
+
+
+def bpr_mf_pull_step(U_old, U_new, I, mU, vU, mI, vI, user, pos, neg, step, lr, loss_partials, workspace,
+                     beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, decoupled=False, inv_batch=None,
+                     gradI_out=None, heavy_threshold=0, err_flag=None):
+    """One whole BPR-MF step (forward, loss, both gradients, dense Adam) without float atomics.
+
+    reference trainers/mf_trainer.py:106-112.  Reads ``U_old``, writes ``U_new`` (distinct
+    buffers, ping-ponged by the caller), updates ``I`` and the Adam state in place; with
+    ``gradI_out`` the item pass emits the dense item gradient instead of applying Adam.
+    """
+    lib = _lib.load()
+    nu, ni, d = _table_dims(U_old, I)
+    B = user.numel()
+    if pos.numel() != B or neg.numel() != B:
+        raise EngineError("user/pos/neg index tensors differ in length")
+    if U_new.shape != U_old.shape or U_new.data_ptr() == U_old.data_ptr():
+        raise EngineError("U_new must be a distinct buffer of U_old's shape")
+    if loss_partials.numel() != LOSS_PARTIALS:
+        raise EngineError(f"loss_partials must hold {LOSS_PARTIALS} floats")
+    if inv_batch is None:
+        inv_batch = 1.0 / B if B else 0.0
+    step_size, bc2_sqrt = adam_scalars(step, lr, beta1, beta2)
+    f32 = torch.float32
+    check(lib.yr_bpr_mf_pull_step(
+        _dev(U_old, f32, "U_old"), _dev(U_new, f32, "U_new"), _dev(I, f32, "I"),
+        _dev(mU, f32, "mU"), _dev(vU, f32, "vU"), _opt(mI, f32, "mI"), _opt(vI, f32, "vI"),
+        _opt(gradI_out, f32, "gradI_out"),
+        _dev(user, torch.int64, "user"), _dev(pos, torch.int64, "pos"), _dev(neg, torch.int64, "neg"),
+        B, d, nu, ni, float(inv_batch), float(lr), float(step_size), float(bc2_sqrt), float(beta1), float(beta2),
+        float(eps), float(weight_decay), OPT_ADAMW if decoupled else OPT_ADAM, int(heavy_threshold),
+        _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
+        _dev(loss_partials, f32, "loss_partials"), _opt(err_flag, torch.int32, "err_flag"), _stream()),
+        "yr_bpr_mf_pull_step")
+
+
 def loss_finalize(loss_partials, scale, loss_out=None, loss_accum=None):
     """loss_out[0] = scale * sum(partials); loss_accum[0] (float64) += the same."""
     lib = _lib.load()
