@@ -1,0 +1,153 @@
+"""CPU: host-side logic that needs no GPU — C-ABI export check, config plumbing, user sharding,
+triplet sampler, split counts, loud failure without a device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "yelprec_engine.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(yr_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads and exports exactly what include/yelprec_engine.h declares
+    (no compute calls here: there is no GPU in this container)."""
+    from yelprecommendation_amd import _lib
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 10
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in _lib.py"
+    assert sorted(_lib.SIGNATURES) == declared
+    assert lib.yr_engine_version() == _lib.ENGINE_VERSION
+    assert lib.yr_engine_arch() == b"gfx950"
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    assert raw.yr_engine_version() == _lib.ENGINE_VERSION
+
+
+def test_header_version_matches_binding():
+    from yelprecommendation_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "yelprec_engine.h")).read()
+    assert int(re.search(r"#define YR_ENGINE_VERSION (\d+)", hdr).group(1)) == _lib.ENGINE_VERSION
+    assert int(re.search(r"#define YR_LOSS_PARTIALS (\d+)", hdr).group(1)) == 2048
+
+
+def test_argument_checks_without_gpu():
+    """Entry points reject bad arguments before touching the device."""
+    from yelprecommendation_amd import _lib
+    lib = _lib.load()
+    assert lib.yr_bpr_mf_pull_workspace_bytes(-1, 10, 10) == -2
+    n = lib.yr_bpr_mf_pull_workspace_bytes(1 << 20, 31668, 38048)
+    assert 50e6 < n < 120e6                      # ~72 B per triplet + per-row tables
+    assert lib.yr_adam_dense(None, None, None, None, 16, 1e-3, 1e-3, 1.0, 0.9, 0.999, 1e-8, 0.0, 0, 0, None) == -2
+    assert lib.yr_adam_dense(None, None, None, None, 0, 1e-3, 1e-3, 1.0, 0.9, 0.999, 1e-8, 0.0, 0, 0, None) == 0
+    assert lib.yr_topk_masked(None, 1, 10, 10, None, None, 0.0, 100, None, None) == -2   # k > 64
+
+
+def test_ops_refuse_cpu_tensors():
+    from yelprecommendation_amd import engine
+    from yelprecommendation_amd._lib import EngineError
+    z = torch.zeros(8, 64)
+    i = torch.zeros(4, dtype=torch.int64)
+    with pytest.raises(EngineError, match="no CPU fallback"):
+        engine.mf_score(z, z, i, i)
+    with pytest.raises(EngineError):
+        engine.adam_dense(z, z, z, z, 1, 1e-3)
+
+
+def test_model_on_cpu_fails_loudly(tmp_path):
+    """cfg.device='cpu' is still a legal name (reference default) but nothing computes there."""
+    from yelprecommendation_amd._lib import EngineError
+    from yelprecommendation_amd.trainers import MFTrainer
+    from yelprecommendation_amd.utils import make_config
+    t = MFTrainer(make_config("MF", device="cpu", model_dir=str(tmp_path)), 20, 30)
+    assert sorted(t.model.state_dict()) == ["item_embedding.weight", "user_embedding.weight"]
+    with pytest.raises(EngineError):
+        t.model(torch.zeros(2, dtype=torch.int64), torch.zeros(2, dtype=torch.int64))
+
+
+def test_config_unpack_model():
+    from yelprecommendation_amd.utils import DEFAULTS, Config, make_config, unpack_model
+    cfg = make_config("NGCF", lr=0.01)
+    assert cfg.embed_size == 64 and cfg.num_orders == 2 and cfg.lr == 0.01 and "model" not in cfg
+    assert make_config("CDAE").hidden_size == 64 and make_config("CDAE").corruption_level == 0.6
+    bad = Config(DEFAULTS)
+    bad["model_name"] = "nope"
+    with pytest.raises(ValueError):
+        unpack_model(bad)
+
+
+def test_base_trainer_surface(tmp_path):
+    from yelprecommendation_amd.trainers import MFTrainer
+    from yelprecommendation_amd.utils import make_config
+    t = MFTrainer(make_config("MF", device="cpu", model_dir=str(tmp_path / "m"), best_metric="recall"), 5, 7)
+    assert os.path.isdir(str(tmp_path / "m"))
+    assert t._is_surpass_best_metric(current=(1.0, 0, 0.5, 0, 0), best=(0.5, 0, 0.4, 0, 0))
+    assert not t._is_surpass_best_metric(current=(0.1, 0, 0.3, 0, 0), best=(0.5, 0, 0.4, 0, 0))
+    with pytest.raises(NotImplementedError, match="Not implemented model: a"):
+        t._model("a")                                   # reference test/trainers/test_base_trainer.py intent
+    with pytest.raises(NotImplementedError):
+        t._optimizer("rmsprop", t.model, 1e-3)
+    assert t._device("tpu") == torch.device("cpu")
+    for name in ("adam", "adamw", "sgd"):
+        assert t._optimizer(name, t.model, 1e-3, 0.0) is not None
+
+
+def test_user_shard_partition():
+    from yelprecommendation_amd.user_shard import UserShard
+    for n, w in ((31668, 8), (10, 3), (7, 8), (64, 1)):
+        shards = [UserShard(n, w, r) for r in range(w)]
+        assert shards[0].lo == 0 and shards[-1].hi == n
+        assert all(a.hi == b.lo for a, b in zip(shards, shards[1:]))
+        assert max(s.size for s in shards) - min(s.size for s in shards) <= 1
+        ids = np.arange(n)
+        owner = shards[0].owner(ids)
+        for s in shards:
+            assert (owner[s.lo:s.hi] == s.rank).all()
+        t_owner = shards[0].owner(torch.arange(n))
+        assert (t_owner.numpy() == owner).all()
+    s = UserShard(10, 3, 1)
+    u = np.array([0, 4, 5, 6, 9]); p = np.array([1, 2, 3, 4, 5])
+    lu, lp = s.select(u, p)
+    assert lu.tolist() == [0, 1, 2] and lp.tolist() == [2, 3, 4]
+
+
+def test_triplet_sampler_and_split():
+    from yelprecommendation_amd.data.synthetic import make_interactions_torch
+    from yelprecommendation_amd.data.triplets import EpochLoader, TripletSampler, split_train_rows
+    u, i = make_interactions_torch(400, 300, 12.0, seed=3)
+    assert int(u.max()) == 399 and int(i.max()) < 300 and (torch.bincount(u) >= 5).all()
+    key = u * 300 + i
+    assert key.unique().numel() == key.numel() and (key[1:] > key[:-1]).all()
+    label = split_train_rows(u, i)
+    cnt = torch.bincount(u)
+    for user in (0, 17, 399):
+        n = int(cnt[user]); lab = label[u == user]
+        n_test = int(np.ceil(0.2 * n)); n_valid = int(np.ceil(0.25 * (n - n_test)))
+        assert int((lab == 2).sum()) == n_test and int((lab == 1).sum()) == n_valid   # sklearn's counts
+    tr = label == 0
+    s = TripletSampler(u[tr], i[tr], 400, 300, seed=1)
+    a, b, c = s.epoch()
+    assert a.numel() == int(tr.sum()) and sorted((a * 300 + b).tolist()) == sorted((u[tr] * 300 + i[tr]).tolist())
+    assert not s._is_positive(a, c).any() and int(c.min()) >= 0 and int(c.max()) < 300
+    batches = list(EpochLoader(s, 128))
+    assert len(batches) == len(EpochLoader(s, 128)) and sum(x["user_id"].numel() for x in batches) == len(s)
+    su, sp, sn = s.stream(3 * len(s) + 5)
+    assert su.numel() == 3 * len(s) + 5
+
+
+def test_numpy_generator_shape():
+    from yelprecommendation_amd.data.synthetic import make_interactions
+    u, i, r = make_interactions(300, 250, 10.0, seed=5, min_item_degree=5)
+    assert u.min() == 0 and u.max() == 299 and i.max() == 249 and set(np.unique(r)) <= {1, 2, 3, 4, 5}
+    assert np.bincount(i).min() >= 5 and np.bincount(u).min() >= 5
+    assert len(set(zip(u.tolist(), i.tolist()))) == len(u)
