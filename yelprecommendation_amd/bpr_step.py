@@ -31,7 +31,10 @@ IMPL_NAMES = {
 class BPRMFStep:
     def __init__(self, U, I, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, optimizer="adam",
                  world_size=1, process_group=None, time_kernels=False, impl="pull", max_batch=0,
-                 heavy_threshold=0):
+                 heavy_threshold=0, state=None):
+        """``state``: optional dict with pre-existing Adam tensors ``mU, vU, mI, vI`` (shared, updated
+        in place) and the step count ``t`` — lets a trainer keep its torch-style optimizer state
+        in sync with the fused step (see MFTrainer)."""
         if optimizer.lower() not in ("adam", "adamw"):
             raise NotImplementedError(f"BPRMFStep: optimizer {optimizer}")
         if impl not in IMPL_NAMES:
@@ -51,9 +54,13 @@ class BPRMFStep:
         need_gI = impl == "atomic" or world_size > 1
         self.gU = torch.zeros_like(U) if need_gU else None
         self.gI = torch.zeros_like(I) if need_gI else None
-        self.mU, self.vU = torch.zeros_like(U), torch.zeros_like(U)
-        self.mI, self.vI = torch.zeros_like(I), torch.zeros_like(I)
-        self.t = 0
+        if state is not None:
+            self.mU, self.vU, self.mI, self.vI = state["mU"], state["vU"], state["mI"], state["vI"]
+            self.t = int(state.get("t", 0))
+        else:
+            self.mU, self.vU = torch.zeros_like(U), torch.zeros_like(U)
+            self.mI, self.vI = torch.zeros_like(I), torch.zeros_like(I)
+            self.t = 0
         self.partials = torch.zeros(engine.LOSS_PARTIALS, dtype=torch.float32, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.loss_accum = torch.zeros(1, dtype=torch.float64, device=dev)

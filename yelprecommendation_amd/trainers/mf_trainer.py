@@ -6,8 +6,10 @@ Same constructor ``MFTrainer(cfg, num_items, num_users)`` and the same
 returns ``(precision, recall, map, ndcg)@top_n``.
 
 Differences underneath (results equal to float rounding):
-* one fused HIP kernel per batch instead of 2 x forward + loss + backward
-  (mf_trainer.py:106-111); the optimizer step also clears the gradients;
+* with Adam/AdamW the whole batch step — 2 x forward, loss, backward, optimizer.step()
+  (mf_trainer.py:106-112) — is ONE engine call (BPRMFStep, csrc/bpr_pull.hip) that shares the
+  optimizer's state tensors; with SGD it is the fused gather/score/scatter-add kernel plus a
+  dense SGD launch;
 * the running loss stays on the device — one host sync per epoch, not per step
   (mf_trainer.py:114 syncs every batch);
 * ``evaluate`` scores all eval users against the whole catalogue on the device with
@@ -18,6 +20,7 @@ import numpy as np
 import torch
 
 from .. import engine
+from ..bpr_step import BPRMFStep
 from ..loss import BPRLoss
 from ..metric import ranking_metrics
 from ..models.mf import MatrixFactorization
@@ -72,16 +75,48 @@ class MFTrainer(BaseTrainer):
         return (data['user_id'].to(dev, non_blocking=True), data['pos_item'].to(dev, non_blocking=True),
                 data['neg_item'].to(dev, non_blocking=True))
 
+    def _fused_step(self):
+        """A BPRMFStep over the model's tables and the optimizer's own Adam state (created on
+        first use exactly as optimizer.step() would), or None when the optimizer is not Adam/AdamW."""
+        from .. import optim
+        if not isinstance(self.optimizer, optim.Adam):
+            return None
+        U, I = self.model.user_embedding.weight, self.model.item_embedding.weight
+        group = self.optimizer.param_groups[0]
+        for p in (U, I):
+            st = self.optimizer.state[p]
+            if not st:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        sU, sI = self.optimizer.state[U], self.optimizer.state[I]
+        return BPRMFStep(U.data, I.data, lr=group["lr"], betas=group["betas"], eps=group["eps"],
+                         weight_decay=group["weight_decay"],
+                         optimizer="adamw" if self.optimizer._decoupled else "adam",
+                         state=dict(mU=sU["exp_avg"], vU=sU["exp_avg_sq"], mI=sI["exp_avg"], vI=sI["exp_avg_sq"],
+                                    t=sU["step"]))
+
     def train(self, train_dataloader) -> float:
         # reference mf_trainer.py:100-116
         self.model.train()
-        self._loss_accum.zero_()
+        step = self._fused_step()
+        if step is None:                                   # SGD: fused fwd/bwd kernel + dense update
+            self._loss_accum.zero_()
+            for data in train_dataloader:
+                user_id, pos_item, neg_item = self._batch(data)
+                self.model.bpr_loss_backward(user_id, pos_item, neg_item, loss_accum=self._loss_accum)
+                self.optimizer.step(zero_grad=True)
+            self.model.check_indices()
+            return float(self._loss_accum.item())
         for data in train_dataloader:
-            user_id, pos_item, neg_item = self._batch(data)
-            self.model.bpr_loss_backward(user_id, pos_item, neg_item, loss_accum=self._loss_accum)
-            self.optimizer.step(zero_grad=True)
-        self.model.check_indices()
-        return float(self._loss_accum.item())
+            step.step(*self._batch(data))
+        # hand the (double-buffered) user table and the step count back to the module / optimizer
+        U, I = self.model.user_embedding.weight, self.model.item_embedding.weight
+        U.data = step.U
+        self.optimizer.state[U]["step"] = self.optimizer.state[I]["step"] = step.t
+        total = step.epoch_loss()
+        step.check()
+        return total
 
     def validate(self, valid_dataloader) -> float:
         # reference mf_trainer.py:118-132
