@@ -1,0 +1,81 @@
+"""GPU: the multi-GPU shape of the BPR-MF step on the one GPU of the test box.
+(1) split item update (item pass emits the dense gradient, separate dense Adam) == fused step;
+(2) two ranks sharing cuda:0 over gloo: user-sharded step == single-process oracle.  RCCL itself
+needs one GPU per rank, so the collective here is gloo; the rest of the path is the product's."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import bpr_mf as obpr
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem():
+    rs = np.random.RandomState(31)
+    nu, ni, d, B, steps = 301, 257, 64, 6000, 3
+    U = (rs.standard_normal((nu, d)) * 0.2).astype(np.float32)
+    I = (rs.standard_normal((ni, d)) * 0.2).astype(np.float32)
+    batches = [(rs.randint(0, nu, B).astype(np.int64), rs.randint(0, ni, B).astype(np.int64),
+                rs.randint(0, ni, B).astype(np.int64)) for _ in range(steps)]
+    return nu, ni, d, B, U, I, batches
+
+
+def test_split_item_update_equals_fused(device):
+    from yelprecommendation_amd.bpr_step import BPRMFStep
+    nu, ni, d, B, U, I, batches = _problem()
+    a = BPRMFStep(torch.from_numpy(U).to(device), torch.from_numpy(I).to(device), lr=5e-3)
+    b = BPRMFStep(torch.from_numpy(U).to(device), torch.from_numpy(I).to(device), lr=5e-3, split_item_update=True)
+    for (u, p, n) in batches:
+        t = [torch.from_numpy(x).to(device) for x in (u, p, n)]
+        a.step(*t)
+        b.step(*t)
+    assert abs(a.epoch_loss() - b.epoch_loss()) < 1e-6
+    torch.testing.assert_close(a.I, b.I, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(a.U, b.U, rtol=1e-4, atol=1e-6)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from yelprecommendation_amd.bpr_step import BPRMFStep
+    from yelprecommendation_amd.user_shard import UserShard
+    dev = torch.device("cuda:0")
+    nu, ni, d, B, U, I, batches = _problem()
+    shard = UserShard(nu, world, rank)
+    step = BPRMFStep(torch.from_numpy(U[shard.lo:shard.hi].copy()).to(dev), torch.from_numpy(I).to(dev), lr=5e-3,
+                     world_size=world, process_group=dist.group.WORLD)
+    for (u, p, n) in batches:
+        lu, lp, ln = shard.select(u, p, n)
+        step.step(*(torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (lu, lp, ln)), global_batch=B)
+    loss = step.epoch_loss()
+    step.check()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), U=step.U.cpu().numpy(), I=step.I.cpu().numpy(),
+             lo=shard.lo, hi=shard.hi, loss=loss)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_match_oracle(tmp_path, device):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    nu, ni, d, B, U, I, batches = _problem()
+    ref = obpr.MFState(U, I, "adam", lr=5e-3)
+    total = sum(float(ref.train_step(u, p, n)) for (u, p, n) in batches)
+    for r in range(world):
+        o = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        np.testing.assert_allclose(o["U"], ref.U[int(o["lo"]):int(o["hi"])], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(o["I"], ref.I, rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(float(o["loss"]), total, rtol=1e-5)

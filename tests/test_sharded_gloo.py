@@ -1,0 +1,88 @@
+"""CPU, world_size 2, gloo: the user-sharded BPR-MF step reproduces the
+single-process step.  The product's exchange protocol (user_shard.sharded_item_exchange — the same
+function bpr_step.BPRMFStep drives with HIP closures on the GPU) is driven here with NumPy-oracle
+closures, so what is checked is the sharding algebra: triplet ownership, inv_batch = 1/B_global,
+the SUM all-reduce of the dense item gradient, identical replicated item updates, loss reduction."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import adam as oadam
+from oracle import bpr_mf as obpr
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _problem():
+    rs = np.random.RandomState(21)
+    nu, ni, d, B, steps = 37, 53, 32, 400, 3
+    U = (rs.standard_normal((nu, d)) * 0.2).astype(np.float32)
+    I = (rs.standard_normal((ni, d)) * 0.2).astype(np.float32)
+    batches = [(rs.randint(0, nu, B).astype(np.int64), rs.randint(0, ni, B).astype(np.int64),
+                rs.randint(0, ni, B).astype(np.int64)) for _ in range(steps)]
+    return nu, ni, d, B, U, I, batches
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from yelprecommendation_amd.user_shard import UserShard, sharded_item_exchange
+    nu, ni, d, B, U, I, batches = _problem()
+    shard = UserShard(nu, world, rank)
+    Ul, Il = U[shard.lo:shard.hi].copy(), I.copy()
+    mU, vU, mI, vI = (np.zeros_like(a) for a in (Ul, Ul, Il, Il))
+    grad_item = torch.zeros(ni, d)
+    loss_sum = torch.zeros(1, dtype=torch.float64)
+    lr = 5e-3
+    for t, (u, p, n) in enumerate(batches, start=1):
+        lu, lp, ln = shard.select(u, p, n)                       # this rank's slice of the GLOBAL batch
+        state = {}
+
+        def local_step():
+            pos, neg = obpr.forward(Ul, Il, lu, lp), obpr.forward(Ul, Il, lu, ln)
+            x = pos - neg
+            scale = np.float32(len(lu)) / np.float32(B)          # bpr_coeff divides by the LOCAL length
+            g = (obpr.bpr_coeff(pos, neg) * scale)[:, None] if len(lu) else np.zeros((0, 1), np.float32)
+            gU, gI = np.zeros_like(Ul), np.zeros_like(Il)
+            np.add.at(gU, lu, g * (Il[lp] - Il[ln]))
+            np.add.at(gI, lp, g * Ul[lu])
+            np.add.at(gI, ln, -g * Ul[lu])
+            state["loss"] = float(np.sum(-obpr.log_sigmoid(x), dtype=np.float64)) / B
+            oadam.adam_update(Ul, gU, mU, vU, t, lr)             # user rows: local
+            grad_item.copy_(torch.from_numpy(gI))
+
+        def item_update():
+            oadam.adam_update(Il, grad_item.numpy().copy(), mI, vI, t, lr)
+
+        sharded_item_exchange(local_step, item_update, grad_item, None, world)
+        loss_sum += state["loss"]
+    dist.all_reduce(loss_sum)                                     # BPRMFStep.epoch_loss
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), U=Ul, I=Il, lo=shard.lo, hi=shard.hi,
+             loss=loss_sum.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_user_sharded_step_equals_single_process(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    nu, ni, d, B, U, I, batches = _problem()
+    ref = obpr.MFState(U, I, "adam", lr=5e-3)
+    total = sum(float(ref.train_step(u, p, n)) for (u, p, n) in batches)
+    outs = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+    assert int(outs[0]["lo"]) == 0 and int(outs[-1]["hi"]) == nu and int(outs[0]["hi"]) == int(outs[1]["lo"])
+    for o in outs:
+        np.testing.assert_allclose(o["U"], ref.U[int(o["lo"]):int(o["hi"])], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(o["I"], ref.I, rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(float(o["loss"][0]), total, rtol=1e-6)
+    np.testing.assert_array_equal(outs[0]["I"], outs[1]["I"])   # replicas stay bit-identical

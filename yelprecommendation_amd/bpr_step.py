@@ -20,6 +20,7 @@ Two implementations of the same step:
 import torch
 
 from . import engine
+from .user_shard import sharded_item_exchange
 
 
 IMPL_NAMES = {
@@ -31,10 +32,13 @@ IMPL_NAMES = {
 class BPRMFStep:
     def __init__(self, U, I, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, optimizer="adam",
                  world_size=1, process_group=None, time_kernels=False, impl="pull", max_batch=0,
-                 heavy_threshold=0, state=None):
+                 heavy_threshold=0, state=None, split_item_update=False):
         """``state``: optional dict with pre-existing Adam tensors ``mU, vU, mI, vI`` (shared, updated
         in place) and the step count ``t`` — lets a trainer keep its torch-style optimizer state
-        in sync with the fused step (see MFTrainer)."""
+        in sync with the fused step (see MFTrainer).
+        ``split_item_update``: take the multi-GPU shape of the step (item pass emits the dense item
+        gradient, then a separate dense Adam launch) even with one rank — used by tests."""
+        self.split_item_update = split_item_update
         if optimizer.lower() not in ("adam", "adamw"):
             raise NotImplementedError(f"BPRMFStep: optimizer {optimizer}")
         if impl not in IMPL_NAMES:
@@ -51,7 +55,7 @@ class BPRMFStep:
         self.world_size, self.pg = world_size, process_group
         dev = U.device
         need_gU = impl == "atomic"
-        need_gI = impl == "atomic" or world_size > 1
+        need_gI = impl == "atomic" or world_size > 1 or split_item_update
         self.gU = torch.zeros_like(U) if need_gU else None
         self.gI = torch.zeros_like(I) if need_gI else None
         if state is not None:
@@ -95,39 +99,48 @@ class BPRMFStep:
         return self._ws
 
     # -- the step -----------------------------------------------------------------------------
-    def step(self, u, p, n, record=False):
+    def step(self, u, p, n, record=False, global_batch=None):
+        """One optimisation step on this rank's triplets.  ``global_batch``: size of the batch
+        over ALL ranks (the mean of loss.py:27 is over it); default = local size x world_size,
+        i.e. equal slices."""
+        if global_batch is None:
+            global_batch = u.numel() * self.world_size
         if self.impl_key == "pull":
-            return self._step_pull(u, p, n, record)
-        return self._step_atomic(u, p, n, record)
+            return self._step_pull(u, p, n, record, global_batch)
+        return self._step_atomic(u, p, n, record, global_batch)
 
-    def _step_pull(self, u, p, n, record):
+    def _step_pull(self, u, p, n, record, global_batch):
         B = u.numel()
         D = self.U.shape[1]
-        inv = 1.0 / (B * self.world_size) if B else 0.0
+        inv = 1.0 / global_batch if global_batch else 0.0
         self.t += 1
         ws = self._workspace(B)
-        multi = self.world_size > 1
+        multi = self.world_size > 1 or self.split_item_update
         nU, nI = self.U.numel(), self.I.numel()
         # algorithmic bytes of the launch group: the per-triplet figure of SURVEY §8d plus the
         # dense Adam pass it absorbs (read p,m,v + write p,m,v on every row of both tables)
         alg = B * (24 + 24 * D) + 6 * 4 * (nU + (0 if multi else nI))
-        self._timed("bpr_pull_step", alg, record, lambda: engine.bpr_mf_pull_step(
-            self.U, self._U_alt, self.I, self.mU, self.vU, self.mI, self.vI, u, p, n, self.t, self.lr,
-            self.partials, ws, self.betas[0], self.betas[1], self.eps, self.wd, self.decoupled, inv_batch=inv,
-            gradI_out=self.gI if multi else None, heavy_threshold=self.heavy_threshold, err_flag=self.flag))
-        self.U, self._U_alt = self._U_alt, self.U
-        if multi:
-            import torch.distributed as dist
-            dist.all_reduce(self.gI, op=dist.ReduceOp.SUM, group=self.pg)
-            self._timed("adam_dense_item", 7 * 4 * nI, record, lambda: engine.adam_dense(
-                self.I, self.gI, self.mI, self.vI, self.t, self.lr, self.betas[0], self.betas[1], self.eps,
-                self.wd, decoupled=self.decoupled, zero_grad=False))
+        def local_step():
+            self._timed("bpr_pull_step", alg, record, lambda: engine.bpr_mf_pull_step(
+                self.U, self._U_alt, self.I, self.mU, self.vU, self.mI, self.vI, u, p, n, self.t, self.lr,
+                self.partials, ws, self.betas[0], self.betas[1], self.eps, self.wd, self.decoupled,
+                inv_batch=inv, gradI_out=self.gI if multi else None, heavy_threshold=self.heavy_threshold,
+                err_flag=self.flag))
+            self.U, self._U_alt = self._U_alt, self.U
+
+        def item_update():
+            if multi:
+                self._timed("adam_dense_item", 7 * 4 * nI, record, lambda: engine.adam_dense(
+                    self.I, self.gI, self.mI, self.vI, self.t, self.lr, self.betas[0], self.betas[1], self.eps,
+                    self.wd, decoupled=self.decoupled, zero_grad=False))
+
+        sharded_item_exchange(local_step, item_update, self.gI, self.pg, self.world_size)
         engine.loss_finalize(self.partials, inv, self.loss, self.loss_accum)
 
-    def _step_atomic(self, u, p, n, record):
+    def _step_atomic(self, u, p, n, record, global_batch):
         B = u.numel()
         D = self.U.shape[1]
-        inv = 1.0 / (B * self.world_size) if B else 0.0
+        inv = 1.0 / global_batch if global_batch else 0.0
         self._timed("bpr_fwd_bwd", B * (24 + 24 * D), record, lambda: engine.bpr_mf_fwd_bwd(
             self.U, self.I, u, p, n, self.gU, self.gI, self.partials, inv_batch=inv, err_flag=self.flag))
         work = None

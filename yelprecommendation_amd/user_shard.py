@@ -46,3 +46,22 @@ class UserShard:
         """Keep the triplets this rank owns; user ids come back localized."""
         m = self.mine(user_id)
         return (self.localize(user_id[m]),) + tuple(o[m] for o in others)
+
+
+def sharded_item_exchange(local_step, item_update, grad_item, group=None, world_size=1):
+    """The one exchange step of the user-sharded BPR-MF step, backend-agnostic:
+
+        local_step()            every rank: forward/backward on ITS triplets with
+                                inv_batch = 1 / B_global; user rows + their Adam state are updated
+                                locally; the dense local item gradient lands in ``grad_item``
+        all_reduce(grad_item)   SUM over ranks (RCCL over xGMI on MI355X; gloo in the CPU tests)
+        item_update()           identical dense Adam on the replicated item table on every rank
+
+    ``bpr_step.BPRMFStep`` passes HIP-kernel closures; the CPU tests pass oracle closures to check
+    that the sharded protocol reproduces the single-process step.
+    """
+    local_step()
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.all_reduce(grad_item, op=dist.ReduceOp.SUM, group=group)
+    item_update()
