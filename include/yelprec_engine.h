@@ -116,7 +116,7 @@ int yr_bpr_mf_fwd_bwd(const float *U, const float *I,
  *   inv_batch: 1 / (global batch size); loss_partials as for yr_bpr_mf_fwd_bwd;
  *   lr..weight_decay, step_size, bc2_sqrt, mode: as for yr_adam_dense;
  *   heavy_threshold: rows with more contributions than this are summed by a whole
- *          1024-thread workgroup instead of one wave (<= 0: default 256);
+ *          256-thread workgroup instead of one wave (<= 0: default 256);
  *   workspace: >= yr_bpr_mf_pull_workspace_bytes(B, num_users, num_items) bytes, 16-byte
  *          aligned, contents irrelevant on entry.
  * ------------------------------------------------------------------------- */

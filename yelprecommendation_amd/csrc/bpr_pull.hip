@@ -22,7 +22,8 @@
 //              occ1[slot] = user | local_item_row << 24  (one per pos/neg occurrence) by item bucket
 //   level 2  one workgroup per bucket counting-sorts the bucket's records by local row in LDS and
 //            writes rec2 / occ2 = {user, level-1 slot} in row order plus the row offsets
-//            offU / offI; rows with more than `heavy` contributions go on a heavy list.
+//            offU / offI; rows with more than `heavy` contributions go on a heavy list (a whole
+//            workgroup sums such a row, one wave every other row).
 //   user pass    row u: x_b = U[u].(I[p_b]-I[n_b]); loss += softplus(-x_b);
 //                g_b = -sigmoid(-x_b)/B; acc += g_b (I[p_b]-I[n_b]);
 //                occ_g[slot_pos] = g_b; occ_g[slot_neg] = -g_b;  U_new[u] = Adam(U[u], acc)
@@ -203,56 +204,62 @@ __global__ __launch_bounds__(kPartThreads) void part_scatter_kernel(const int64_
 // One workgroup per bucket: counting sort of the bucket's records by local row.
 constexpr int kSortThreads = 256;
 
-template <bool USER>
-__global__ __launch_bounds__(kSortThreads) void bucket_sort_kernel(const int32_t* __restrict__ base, int buckets,
-                                                                   int rows, const int4* __restrict__ rec1,
+struct SortSide {
+  const int32_t* base;     // [buckets + 1]
+  int32_t* off;            // [rows + 1]
+  int32_t* heavy;
+  int32_t* nheavy;
+  int buckets, rows;
+};
+
+// blocks [0, U.buckets) sort user buckets (rec1 -> rec2), the rest item buckets (occ1 -> occ2)
+__global__ __launch_bounds__(kSortThreads) void bucket_sort_kernel(SortSide su, SortSide si,
+                                                                   const int4* __restrict__ rec1,
                                                                    const int32_t* __restrict__ occ1,
                                                                    int4* __restrict__ rec2, int2* __restrict__ occ2,
-                                                                   int32_t* __restrict__ off, int heavy_t,
-                                                                   int32_t* __restrict__ heavy,
-                                                                   int32_t* __restrict__ nheavy) {
+                                                                   int heavy_t) {
   __shared__ int s_cnt[kBucketRows];
   __shared__ int s_start[kBucketRows];
-  for (int bucket = blockIdx.x; bucket < buckets; bucket += gridDim.x) {
-    const int lo = base[bucket], hi = base[bucket + 1];
-    const int row0 = bucket * kBucketRows;
-    if (threadIdx.x < kBucketRows) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    for (int i = lo + threadIdx.x; i < hi; i += kSortThreads) {
-      const uint32_t w = USER ? (uint32_t)rec1[i].y : (uint32_t)occ1[i];
-      atomicAdd(&s_cnt[w >> kLocalShift], 1);
-    }
-    __syncthreads();
-    if (threadIdx.x < kWave) {                     // wave 0: exclusive scan of the 64 row counts
-      const int c = s_cnt[threadIdx.x];
-      int inc = c;
+  const bool user = (int)blockIdx.x < su.buckets;
+  const SortSide& sd = user ? su : si;
+  const int bucket = user ? blockIdx.x : blockIdx.x - su.buckets;
+  const int lo = sd.base[bucket], hi = sd.base[bucket + 1];
+  const int row0 = bucket * kBucketRows;
+  if (threadIdx.x < kBucketRows) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = lo + threadIdx.x; i < hi; i += kSortThreads) {
+    const uint32_t w = user ? (uint32_t)rec1[i].y : (uint32_t)occ1[i];
+    atomicAdd(&s_cnt[w >> kLocalShift], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < kWave) {                     // wave 0: exclusive scan of the 64 row counts
+    const int c = s_cnt[threadIdx.x];
+    int inc = c;
 #pragma unroll
-      for (int d = 1; d < kWave; d <<= 1) {
-        const int o = __shfl_up(inc, d, kWave);
-        if ((int)threadIdx.x >= d) inc += o;
-      }
-      const int start = lo + inc - c;
-      s_start[threadIdx.x] = start;
-      const int row = row0 + threadIdx.x;
-      if (row < rows) {
-        off[row] = start;
-        if (c > heavy_t) heavy[atomicAdd(nheavy, 1)] = row;
-      }
-      if (row == rows - 1) off[rows] = start + c;
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int o = __shfl_up(inc, d, kWave);
+      if ((int)threadIdx.x >= d) inc += o;
     }
-    __syncthreads();
-    for (int i = lo + threadIdx.x; i < hi; i += kSortThreads) {
-      if (USER) {
-        int4 r = rec1[i];
-        const int local = (uint32_t)r.y >> kLocalShift;
-        r.y &= kIdMask;
-        rec2[atomicAdd(&s_start[local], 1)] = r;
-      } else {
-        const uint32_t w = (uint32_t)occ1[i];
-        occ2[atomicAdd(&s_start[w >> kLocalShift], 1)] = make_int2((int)(w & kIdMask), i);
-      }
+    const int start = lo + inc - c;
+    s_start[threadIdx.x] = start;
+    const int row = row0 + threadIdx.x;
+    if (row < sd.rows) {
+      sd.off[row] = start;
+      if (c > heavy_t) sd.heavy[atomicAdd(sd.nheavy, 1)] = row;
     }
-    __syncthreads();
+    if (row == sd.rows - 1) sd.off[sd.rows] = start + c;
+  }
+  __syncthreads();
+  for (int i = lo + threadIdx.x; i < hi; i += kSortThreads) {
+    if (user) {
+      int4 r = rec1[i];
+      const int local = (uint32_t)r.y >> kLocalShift;
+      r.y &= kIdMask;
+      rec2[atomicAdd(&s_start[local], 1)] = r;
+    } else {
+      const uint32_t w = (uint32_t)occ1[i];
+      occ2[atomicAdd(&s_start[w >> kLocalShift], 1)] = make_int2((int)(w & kIdMask), i);
+    }
   }
 }
 
@@ -284,36 +291,62 @@ struct PullGeom {
   static constexpr int GPW = kWave / LPR;      // contributions per wave pass
 };
 
-constexpr int kPullUnroll = 2;
+// contributions in flight per lane group: the user pass is VALU-heavier and holds two rows per
+// contribution, the item pass is pure latency
+template <bool USER>
+struct PullUnroll {
+  static constexpr int N = USER ? 2 : 4;
+};
+
+// The index words of one contribution: user pass {pos, neg, slot_pos, slot_neg}; item pass {user, slot}.
+template <bool USER>
+__device__ __forceinline__ int4 load_index(const RowPassArgs& a, int idx, bool valid) {
+  if (!valid) return make_int4(0, 0, 0, 0);
+  if (USER) return a.rec[idx];
+  const int2 o = a.occ[idx];
+  return make_int4(o.x, o.y, 0, 0);
+}
 
 // Accumulate the contributions [lo, hi) of one row, visiting indices base + first + k*step.
-// Adds into this lane group's partial gradient (float4 at column 4*l) and loss.
+// Adds into this lane group's partial gradient (float4 at column 4*l) and loss.  Software
+// pipelined: the index words of the NEXT pass are loaded before the rows of this one are used,
+// so the dependent chain index -> row never leaves the wave without loads in flight.
 template <int D, bool USER>
 __device__ __forceinline__ void pull_accumulate(const RowPassArgs& a, int lo, int hi, int first, int step,
                                                 const float4& own, int l, float4& acc, float& loss) {
   using G = PullGeom<D>;
-  // uniform trip count across the wave / workgroup: the start is common, `first` only offsets idx
-  for (int base = lo; base < hi; base += step * kPullUnroll) {
-    float4 r0[kPullUnroll], r1[kPullUnroll];
-    int4 rec[kPullUnroll];
-    float g[kPullUnroll];
-    bool valid[kPullUnroll];
+  constexpr int N = PullUnroll<USER>::N;
+  int4 cur[N], nxt[N];
+  bool cur_valid[N];
 #pragma unroll
-    for (int q = 0; q < kPullUnroll; ++q) {
-      const int idx = base + first + q * step;
-      valid[q] = idx < hi;
+  for (int q = 0; q < N; ++q) {
+    const int idx = lo + first + q * step;
+    cur_valid[q] = idx < hi;
+    cur[q] = load_index<USER>(a, idx, cur_valid[q]);
+  }
+  // uniform trip count across the wave / workgroup: the start is common, `first` only offsets idx
+  for (int base = lo; base < hi; base += step * N) {
+    float4 r0[N], r1[N];
+    float g[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
       if (USER) {
-        rec[q] = valid[q] ? a.rec[idx] : make_int4(0, 0, 0, 0);
-        r0[q] = ld4(a.other + (int64_t)rec[q].x * D + 4 * l);
-        r1[q] = ld4(a.other + (int64_t)rec[q].y * D + 4 * l);
+        r0[q] = ld4(a.other + (int64_t)cur[q].x * D + 4 * l);
+        r1[q] = ld4(a.other + (int64_t)cur[q].y * D + 4 * l);
       } else {
-        const int2 o = valid[q] ? a.occ[idx] : make_int2(0, 0);
-        g[q] = valid[q] ? a.occ_g[o.y] : 0.0f;
-        r0[q] = ld4(a.other + (int64_t)o.x * D + 4 * l);
+        g[q] = cur_valid[q] ? a.occ_g[cur[q].y] : 0.0f;
+        r0[q] = ld4(a.other + (int64_t)cur[q].x * D + 4 * l);
       }
     }
+    bool nxt_valid[N];
 #pragma unroll
-    for (int q = 0; q < kPullUnroll; ++q) {
+    for (int q = 0; q < N; ++q) {
+      const int idx = base + step * N + first + q * step;
+      nxt_valid[q] = idx < hi;
+      nxt[q] = load_index<USER>(a, idx, nxt_valid[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
       if (USER) {
         float4 d;
         d.x = r0[q].x - r1[q].x; d.y = r0[q].y - r1[q].y; d.z = r0[q].z - r1[q].z; d.w = r0[q].w - r1[q].w;
@@ -321,19 +354,26 @@ __device__ __forceinline__ void pull_accumulate(const RowPassArgs& a, int lo, in
         part = fmaf(own.y, d.y, part);
         part = fmaf(own.z, d.z, part);
         part = fmaf(own.w, d.w, part);
-        const float x = group_sum<G::LPR>(part);
-        const float gg = valid[q] ? -sigmoid_neg(x) * a.inv_batch : 0.0f;
+        const float x = group_sum_dpp<G::LPR>(part);
+        float sp, sg;
+        bpr_terms(x, sp, sg);
+        const float gg = cur_valid[q] ? -sg * a.inv_batch : 0.0f;
         acc.x = fmaf(gg, d.x, acc.x); acc.y = fmaf(gg, d.y, acc.y);
         acc.z = fmaf(gg, d.z, acc.z); acc.w = fmaf(gg, d.w, acc.w);
-        if (valid[q] && l == 0) {
-          a.occ_g[rec[q].z] = gg;
-          a.occ_g[rec[q].w] = -gg;
-          loss += softplus_neg(x);
+        if (cur_valid[q] && l == 0) {
+          a.occ_g[cur[q].z] = gg;
+          a.occ_g[cur[q].w] = -gg;
+          loss += sp;
         }
       } else {
         acc.x = fmaf(g[q], r0[q].x, acc.x); acc.y = fmaf(g[q], r0[q].y, acc.y);
         acc.z = fmaf(g[q], r0[q].z, acc.z); acc.w = fmaf(g[q], r0[q].w, acc.w);
       }
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      cur[q] = nxt[q];
+      cur_valid[q] = nxt_valid[q];
     }
   }
 }
@@ -367,73 +407,55 @@ __device__ __forceinline__ void finish_row(const RowPassArgs& a, int row, float4
   }
 }
 
-// one wave per row; rows with more than heavy_t contributions are left to the heavy kernel
+// One launch per table.  Workgroups [0, kHeavyBlocks) walk the heavy-row list, a whole workgroup
+// (4 waves) per row with an LDS reduction; the others give one wave to each remaining row.  The
+// heavy workgroups have the lowest ids, so they start first and their long rows overlap the rest.
+constexpr int kHeavyBlocks = 512;
 template <int D, bool USER, bool FUSE_ADAM>
-__global__ __launch_bounds__(kBlock) void pull_rows_light_kernel(RowPassArgs a) {
+__global__ __launch_bounds__(kBlock) void pull_rows_kernel(RowPassArgs a) {
   using G = PullGeom<D>;
+  __shared__ float4 s_acc[kWavesPerBlock][G::LPR];
   __shared__ float s_red[kWavesPerBlock];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int grp = lane / G::LPR, l = lane % G::LPR;
-  const int nwaves = gridDim.x * kWavesPerBlock;
   float loss = 0.0f;
-  for (int row = blockIdx.x * kWavesPerBlock + wave; row < a.rows; row += nwaves) {
-    const int lo = a.off[row], hi = a.off[row + 1];
-    if (hi - lo > a.heavy_t) continue;
-    const float4 own = ld4(a.own_old + (int64_t)row * D + 4 * l);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    pull_accumulate<D, USER>(a, lo, hi, grp, G::GPW, own, l, acc, loss);
-    cross_group_sum<G::LPR>(acc);
-    if (grp == 0) finish_row<D, FUSE_ADAM>(a, row, own, acc, l);
+  if ((int)blockIdx.x < kHeavyBlocks) {
+    const int nh = a.nheavy[0];
+    for (int h = blockIdx.x; h < nh; h += kHeavyBlocks) {
+      const int row = a.heavy[h];
+      const int lo = a.off[row], hi = a.off[row + 1];
+      const float4 own = ld4(a.own_old + (int64_t)row * D + 4 * l);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      pull_accumulate<D, USER>(a, lo, hi, wave * G::GPW + grp, kWavesPerBlock * G::GPW, own, l, acc, loss);
+      cross_group_sum<G::LPR>(acc);
+      if (grp == 0) s_acc[wave][l] = acc;
+      __syncthreads();
+      if (wave == 0 && grp == 0) {
+        float4 t = s_acc[0][l];
+#pragma unroll
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+          const float4 o = s_acc[w][l];
+          t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+        }
+        finish_row<D, FUSE_ADAM>(a, row, own, t, l);
+      }
+      __syncthreads();
+    }
+  } else {
+    const int nwaves = (gridDim.x - kHeavyBlocks) * kWavesPerBlock;
+    for (int row = (blockIdx.x - kHeavyBlocks) * kWavesPerBlock + wave; row < a.rows; row += nwaves) {
+      const int lo = a.off[row], hi = a.off[row + 1];
+      if (hi - lo > a.heavy_t) continue;
+      const float4 own = ld4(a.own_old + (int64_t)row * D + 4 * l);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      pull_accumulate<D, USER>(a, lo, hi, grp, G::GPW, own, l, acc, loss);
+      cross_group_sum<G::LPR>(acc);
+      if (grp == 0) finish_row<D, FUSE_ADAM>(a, row, own, acc, l);
+    }
   }
   if (USER) {
     const float total = block_sum(loss, s_red);
     if (threadIdx.x == 0) a.loss_partials[blockIdx.x] = total;
-  }
-}
-
-// one 1024-thread workgroup per heavy row
-constexpr int kHeavyThreads = 1024;
-constexpr int kHeavyWaves = kHeavyThreads / kWave;
-constexpr int kHeavyGrid = 512;
-template <int D, bool USER, bool FUSE_ADAM>
-__global__ __launch_bounds__(kHeavyThreads) void pull_rows_heavy_kernel(RowPassArgs a, int partial_base) {
-  using G = PullGeom<D>;
-  __shared__ float4 s_acc[kHeavyWaves][G::LPR];
-  __shared__ float s_loss[kHeavyWaves];
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  const int grp = lane / G::LPR, l = lane % G::LPR;
-  const int nh = a.nheavy[0];
-  float loss = 0.0f;
-  for (int h = blockIdx.x; h < nh; h += gridDim.x) {
-    const int row = a.heavy[h];
-    const int lo = a.off[row], hi = a.off[row + 1];
-    const float4 own = ld4(a.own_old + (int64_t)row * D + 4 * l);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    pull_accumulate<D, USER>(a, lo, hi, wave * G::GPW + grp, kHeavyWaves * G::GPW, own, l, acc, loss);
-    cross_group_sum<G::LPR>(acc);
-    if (grp == 0) s_acc[wave][l] = acc;
-    __syncthreads();
-    if (wave == 0 && grp == 0) {
-      float4 t = s_acc[0][l];
-#pragma unroll
-      for (int w = 1; w < kHeavyWaves; ++w) {
-        const float4 o = s_acc[w][l];
-        t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
-      }
-      finish_row<D, FUSE_ADAM>(a, row, own, t, l);
-    }
-    __syncthreads();
-  }
-  if (USER) {
-    loss = wave_sum(loss);
-    if (lane == 0) s_loss[wave] = loss;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float t = 0.0f;
-#pragma unroll
-      for (int w = 0; w < kHeavyWaves; ++w) t += s_loss[w];
-      a.loss_partials[partial_base + blockIdx.x] = t;
-    }
   }
 }
 
@@ -509,26 +531,25 @@ static int pull_step_impl(const float* U_old, float* U_new, float* I, float* mU,
     hipLaunchKernelGGL(part_scatter_kernel, dim3(ptiles), dim3(kPartThreads), (size_t)nb_all * 8, s, user, pos, neg,
                        B, nU, nI, w.nbU, nb_all, w.cur_all, w.rec1, w.occ1);
   // 2. level-2 sort inside every bucket -> row offsets, records in row order, heavy lists
-  hipLaunchKernelGGL((bucket_sort_kernel<true>), dim3(w.nbU < 4096 ? w.nbU : 4096), dim3(kSortThreads), 0, s,
-                     w.baseU, w.nbU, (int)nU, w.rec1, nullptr, w.rec2, nullptr, w.offU, heavy_t, w.heavyU, w.nheavy);
-  hipLaunchKernelGGL((bucket_sort_kernel<false>), dim3(w.nbI < 4096 ? w.nbI : 4096), dim3(kSortThreads), 0, s,
-                     w.baseI, w.nbI, (int)nI, nullptr, w.occ1, nullptr, w.occ2, w.offI, heavy_t, w.heavyI,
-                     w.nheavy + 1);
+  SortSide su, si;
+  su.base = w.baseU; su.off = w.offU; su.heavy = w.heavyU; su.nheavy = w.nheavy; su.buckets = w.nbU; su.rows = (int)nU;
+  si.base = w.baseI; si.off = w.offI; si.heavy = w.heavyI; si.nheavy = w.nheavy + 1; si.buckets = w.nbI; si.rows = (int)nI;
+  hipLaunchKernelGGL(bucket_sort_kernel, dim3(nb_all), dim3(kSortThreads), 0, s, su, si, w.rec1, w.occ1, w.rec2,
+                     w.occ2, heavy_t);
   // 3. user pass (reads U_old + I, writes U_new, occ_g, loss partials)
   RowPassArgs ua;
   ua.own_old = U_old; ua.own_new = U_new; ua.other = I; ua.m = mU; ua.v = vU; ua.grad_out = nullptr;
   ua.off = w.offU; ua.rec = w.rec2; ua.occ = nullptr; ua.occ_g = w.occ_g;
   ua.heavy = w.heavyU; ua.nheavy = w.nheavy; ua.loss_partials = loss_partials;
   ua.rows = (int)nU; ua.heavy_t = heavy_t; ua.inv_batch = inv_batch; ua.adam = adam;
-  const int light_cap = YR_LOSS_PARTIALS - kHeavyGrid;          // partial slots [0, cap) light, rest heavy
+  const int light_cap = YR_LOSS_PARTIALS - kHeavyBlocks;        // one loss-partial slot per workgroup
   int gu = (int)((nU + kWavesPerBlock - 1) / kWavesPerBlock);
   if (gu > light_cap) gu = light_cap;
-  hipLaunchKernelGGL((pull_rows_heavy_kernel<D, true, true>), dim3(kHeavyGrid), dim3(kHeavyThreads), 0, s, ua,
-                     light_cap);
-  hipLaunchKernelGGL((pull_rows_light_kernel<D, true, true>), dim3(gu), dim3(kBlock), 0, s, ua);
-  if (gu < light_cap)
-    hipLaunchKernelGGL(pull_clear_partials_kernel, dim3((light_cap - gu + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
-                       loss_partials, gu, light_cap);
+  gu += kHeavyBlocks;
+  hipLaunchKernelGGL((pull_rows_kernel<D, true, true>), dim3(gu), dim3(kBlock), 0, s, ua);
+  if (gu < YR_LOSS_PARTIALS)
+    hipLaunchKernelGGL(pull_clear_partials_kernel, dim3((YR_LOSS_PARTIALS - gu + kBlock - 1) / kBlock), dim3(kBlock),
+                       0, s, loss_partials, gu, YR_LOSS_PARTIALS);
   // 4. item pass (reads U_old + occ_*, updates I in place or writes gradI_out)
   RowPassArgs ia;
   ia.own_old = I; ia.own_new = I; ia.other = U_old; ia.m = mI; ia.v = vI; ia.grad_out = gradI_out;
@@ -537,13 +558,11 @@ static int pull_step_impl(const float* U_old, float* U_new, float* I, float* mU,
   ia.rows = (int)nI; ia.heavy_t = heavy_t; ia.inv_batch = inv_batch; ia.adam = adam;
   int gi = (int)((nI + kWavesPerBlock - 1) / kWavesPerBlock);
   if (gi > kMaxGrid) gi = kMaxGrid;
-  if (gradI_out) {
-    hipLaunchKernelGGL((pull_rows_heavy_kernel<D, false, false>), dim3(kHeavyGrid), dim3(kHeavyThreads), 0, s, ia, 0);
-    hipLaunchKernelGGL((pull_rows_light_kernel<D, false, false>), dim3(gi), dim3(kBlock), 0, s, ia);
-  } else {
-    hipLaunchKernelGGL((pull_rows_heavy_kernel<D, false, true>), dim3(kHeavyGrid), dim3(kHeavyThreads), 0, s, ia, 0);
-    hipLaunchKernelGGL((pull_rows_light_kernel<D, false, true>), dim3(gi), dim3(kBlock), 0, s, ia);
-  }
+  gi += kHeavyBlocks;
+  if (gradI_out)
+    hipLaunchKernelGGL((pull_rows_kernel<D, false, false>), dim3(gi), dim3(kBlock), 0, s, ia);
+  else
+    hipLaunchKernelGGL((pull_rows_kernel<D, false, true>), dim3(gi), dim3(kBlock), 0, s, ia);
   return launch_status();
 }
 

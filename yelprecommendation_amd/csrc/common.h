@@ -34,6 +34,40 @@ __device__ __forceinline__ float group_sum(float x) {
 
 __device__ __forceinline__ float wave_sum(float x) { return group_sum<kWave>(x); }
 
+// x + (x moved across lanes by a DPP control); all lanes active
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false);
+  return x + __int_as_float(moved);
+}
+
+// Sum over aligned groups of LPR lanes using DPP (no LDS crossbar traffic): quad swaps, then the
+// mirror forms inside a 16-lane DPP row; 32-lane groups add one cross-row shuffle.
+template <int LPR>
+__device__ __forceinline__ float group_sum_dpp(float x) {
+  static_assert(LPR == 4 || LPR == 8 || LPR == 16 || LPR == 32, "group size");
+  x = dpp_add<0xB1>(x);                      // quad_perm [1,0,3,2]
+  x = dpp_add<0x4E>(x);                      // quad_perm [2,3,0,1]
+  if (LPR >= 8) x = dpp_add<0x141>(x);       // row_half_mirror
+  if (LPR >= 16) x = dpp_add<0x140>(x);      // row_mirror
+  if (LPR >= 32) x += __shfl_xor(x, 16, kWave);
+  return x;
+}
+
+// Fast transcendental forms (v_exp_f32 / v_log_f32 / v_rcp_f32, about 1 ulp each) for the
+// per-triplet sigmoid / softplus: the library expf/log1pf/IEEE divide cost ~10x the instructions.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// (softplus(-x), sigmoid(-x)) from one exponential
+__device__ __forceinline__ void bpr_terms(float x, float& softplus_negx, float& sigmoid_negx) {
+  const float z = fast_exp(-fabsf(x));
+  const float r = fast_rcp(1.0f + z);
+  sigmoid_negx = x < 0.0f ? r : z * r;
+  softplus_negx = fmaxf(-x, 0.0f) + fast_log(1.0f + z);
+}
+
 // softplus(-x) = -logsigmoid(x) = max(-x, 0) + log1p(exp(-|x|))
 __device__ __forceinline__ float softplus_neg(float x) {
   return fmaxf(-x, 0.0f) + log1pf(expf(-fabsf(x)));
