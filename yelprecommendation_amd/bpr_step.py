@@ -72,6 +72,19 @@ class BPRMFStep:
         self.time_kernels = time_kernels
         self._ev = {}
         self._bytes = {}
+        # validate the long-lived buffers once and cache their addresses for the lean step path
+        from . import _lib
+        self._lib = _lib.load()
+        f32 = torch.float32
+        for name, t in (("U", U), ("I", I), ("mU", self.mU), ("vU", self.vU), ("mI", self.mI), ("vI", self.vI)):
+            engine._dev(t, f32, name)
+        if U.dim() != 2 or I.dim() != 2 or U.shape[1] != I.shape[1]:
+            raise engine.EngineError("tables must be [rows, D] with equal D")
+        if self.mU.shape != U.shape or self.vU.shape != U.shape or self.mI.shape != I.shape or self.vI.shape != I.shape:
+            raise engine.EngineError("Adam state must match the table shapes")
+        self._pI, self._pmU, self._pvU = I.data_ptr(), self.mU.data_ptr(), self.vU.data_ptr()
+        self._pmI, self._pvI = self.mI.data_ptr(), self.vI.data_ptr()
+        self._ppartials, self._pflag = self.partials.data_ptr(), self.flag.data_ptr()
 
     # -- timing of individual kernels with events on the launch stream ------------------------
     def reset_timers(self):
@@ -120,12 +133,26 @@ class BPRMFStep:
         # algorithmic bytes of the launch group: the per-triplet figure of SURVEY §8d plus the
         # dense Adam pass it absorbs (read p,m,v + write p,m,v on every row of both tables)
         alg = B * (24 + 24 * D) + 6 * 4 * (nU + (0 if multi else nI))
+
+        def launch():
+            # lean host path (this call is the whole step): index tensors are checked here, the
+            # long-lived buffers were checked when they were created
+            for name, t in (("user", u), ("pos", p), ("neg", n)):
+                if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.numel() == B):
+                    raise engine.EngineError(f"{name}: need a contiguous int64 GPU tensor of length {B}")
+            step_size, bc2_sqrt = engine.adam_scalars(self.t, self.lr, self.betas[0], self.betas[1])
+            rc = self._lib.yr_bpr_mf_pull_step(
+                self.U.data_ptr(), self._U_alt.data_ptr(), self._pI, self._pmU, self._pvU, self._pmI, self._pvI,
+                self.gI.data_ptr() if multi else None, u.data_ptr(), p.data_ptr(), n.data_ptr(),
+                B, D, self.U.shape[0], self.I.shape[0], inv, self.lr, step_size, bc2_sqrt,
+                self.betas[0], self.betas[1], self.eps, self.wd,
+                engine.OPT_ADAMW if self.decoupled else engine.OPT_ADAM, self.heavy_threshold,
+                ws.data_ptr(), ws.numel(), self._ppartials, self._pflag, torch.cuda.current_stream().cuda_stream)
+            if rc:
+                engine.check(rc, "yr_bpr_mf_pull_step")
+
         def local_step():
-            self._timed("bpr_pull_step", alg, record, lambda: engine.bpr_mf_pull_step(
-                self.U, self._U_alt, self.I, self.mU, self.vU, self.mI, self.vI, u, p, n, self.t, self.lr,
-                self.partials, ws, self.betas[0], self.betas[1], self.eps, self.wd, self.decoupled,
-                inv_batch=inv, gradI_out=self.gI if multi else None, heavy_threshold=self.heavy_threshold,
-                err_flag=self.flag))
+            self._timed("bpr_pull_step", alg, record, launch)
             self.U, self._U_alt = self._U_alt, self.U
 
         def item_update():
@@ -135,7 +162,10 @@ class BPRMFStep:
                     self.wd, decoupled=self.decoupled, zero_grad=False))
 
         sharded_item_exchange(local_step, item_update, self.gI, self.pg, self.world_size)
-        engine.loss_finalize(self.partials, inv, self.loss, self.loss_accum)
+        rc = self._lib.yr_loss_finalize(self._ppartials, inv, self.loss.data_ptr(), self.loss_accum.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream)
+        if rc:
+            engine.check(rc, "yr_loss_finalize")
 
     def _step_atomic(self, u, p, n, record, global_batch):
         B = u.numel()
