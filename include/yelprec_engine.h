@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 4
+#define YR_ENGINE_VERSION 5
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -135,6 +135,18 @@ int yr_bpr_mf_pull_step(const float *U_old, float *U_new, float *I,
  *  loss_accum is float64 like the Python float it replaces.)                        */
 int yr_loss_finalize(const float *loss_partials, float scale,
                      float *loss_out, double *loss_accum, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Full-catalogue scores for evaluation      (reference trainers/mf_trainer.py:138-140:
+ *   for each eval user  pred = model([user] * num_items, arange(num_items)) )
+ *   scores[r, j] = U[users[r]] . I[j]   for r < nrows, j < num_items
+ * as one float32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32 products and
+ * fma-chained accumulation, so rankings match the CPU reference except at float near-ties).
+ * scores: [nrows, row_stride] floats, row_stride >= num_items.  Feed to yr_topk_masked.
+ * ------------------------------------------------------------------------- */
+int yr_mf_scores_gemm(const float *U, const float *I, const int64_t *users, int64_t nrows, int D,
+                      int64_t num_users, int64_t num_items, float *scores, int64_t row_stride,
+                      int32_t *err_flag, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Masked row-wise top-k      (reference trainers/mf_trainer.py:163-178,

@@ -186,21 +186,38 @@ def topk_masked(scores, mask_ptr, mask_idx, k, mask_value=MASK_VALUE, out=None):
     return out
 
 
-def mf_recommend(U, I, users, mask_ptr, mask_idx, k, chunk_users=512):
+def mf_scores_gemm(U, I, users, out=None, err_flag=None):
+    """scores[r, j] = U[users[r]] . I[j] for every item j — the reference's per-user
+    ``model([u]*I, arange(I))`` (trainers/mf_trainer.py:138-140) as one f32 MFMA GEMM."""
+    lib = _lib.load()
+    nu, ni, d = _table_dims(U, I)
+    n = users.numel()
+    if out is None:
+        out = torch.empty((n, ni), dtype=torch.float32, device=U.device)
+    if out.dim() != 2 or out.shape[0] < n or out.shape[1] < ni or out.stride(1) != 1:
+        raise EngineError("scores buffer must be [>= rows, >= num_items] with unit column stride")
+    check(lib.yr_mf_scores_gemm(_dev(U, torch.float32, "U"), _dev(I, torch.float32, "I"),
+                                _dev(users, torch.int64, "users"), n, d, nu, ni, out.data_ptr(), out.stride(0),
+                                _opt(err_flag, torch.int32, "err_flag"), _stream()), "yr_mf_scores_gemm")
+    return out[:n]
+
+
+def mf_recommend(U, I, users, mask_ptr, mask_idx, k, chunk_users=4096):
     """Top-k unmasked items for each user id in ``users`` (reference
     trainers/mf_trainer.py:134-144 + :163-178, batched): full-catalogue scores
-    ``U[users] @ I^T`` with the per-user mask and the top-k selection on the device."""
+    ``U[users] @ I^T`` on the matrix cores, then per-user mask + top-k, all on the device."""
     nu_tab, ni, d = _table_dims(U, I)
     n = users.numel()
     out = torch.empty((n, k), dtype=torch.int64, device=U.device)
-    items = torch.arange(ni, dtype=torch.int64, device=U.device)
     flag = new_error_flag(U.device)
+    chunk_users = max(1, min(chunk_users, n))
+    scores = torch.empty((chunk_users, ni), dtype=torch.float32, device=U.device)
+    ptr_host = mask_ptr.cpu()
     for lo in range(0, n, chunk_users):
         hi = min(lo + chunk_users, n)
-        uu = users[lo:hi]
-        scores = mf_score(U, I, uu.repeat_interleave(ni), items.repeat(hi - lo), err_flag=flag)
+        mf_scores_gemm(U, I, users[lo:hi].contiguous(), out=scores, err_flag=flag)
         ptr = (mask_ptr[lo:hi + 1] - mask_ptr[lo]).contiguous()
-        topk_masked(scores.view(hi - lo, ni), ptr, mask_idx[int(mask_ptr[lo]):], k, out=out[lo:hi])
+        topk_masked(scores[:hi - lo], ptr, mask_idx[int(ptr_host[lo]):], k, out=out[lo:hi])
     raise_on_flag(flag, "mf_recommend")
     return out
 
