@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 5
+#define YR_ENGINE_VERSION 6
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -129,6 +129,34 @@ int yr_bpr_mf_pull_step(const float *U_old, float *U_new, float *I,
                         double beta1, double beta2, double eps, double weight_decay, int mode,
                         int heavy_threshold, void *workspace, int64_t workspace_bytes,
                         float *loss_partials, int32_t *err_flag, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * NGCF message passing            (reference models/ngcf.py:60-72, embedding_propagation:
+ *   E' = leaky_relu( W1((L + I) E) + W2(E * (L E)) ), slope 0.01, Linear(x) = x @ W^T)
+ *
+ * yr_spmm_csr: Y = L X (accumulate = 0) or Y += L X (accumulate != 0), L in CSR with int32
+ *   rowptr[n+1] / col[nnz] and float32 val[nnz], X and Y [n, D] (distinct buffers).
+ *   replaces torch.sparse.mm(L, E) (models/ngcf.py:64,67; COO in the reference) — one SpMM
+ *   serves both terms since (L + I)E = LE + E (no eye(N, N) temporary).  `heavy_rows` (may be
+ *   NULL with n_heavy = 0) must list EXACTLY the rows with more than `heavy_threshold`
+ *   non-zeros; a whole workgroup sums such a row, one wave every other row.
+ * yr_ngcf_dense_fwd: Eout = leaky_relu((Z + E) W1^T + (E * Z) W2^T), W1/W2 [D, D] ([out, in]).
+ * yr_ngcf_dense_bwd_data: dP = dEout * leaky_relu'(Eout); dZ = dP W1 + (dP W2) * E;
+ *   dE += dP W1 + (dP W2) * Z.   W1T / W2T are the TRANSPOSED weights ([in, out] row-major).
+ * yr_ngcf_dense_bwd_weight: dW1 += dP^T (Z + E); dW2 += dP^T (E * Z)   (float atomics on the
+ *   2 D^2 outputs; caller zero-fills).
+ * The backward SpMM (dE += L^T dZ) is yr_spmm_csr with accumulate = 1: L is symmetric.
+ * ------------------------------------------------------------------------- */
+int yr_spmm_csr(const int32_t *rowptr, const int32_t *col, const float *val,
+                const float *X, float *Y, int64_t n, int D, int accumulate,
+                const int32_t *heavy_rows, int64_t n_heavy, int heavy_threshold, void *stream);
+int yr_ngcf_dense_fwd(const float *E, const float *Z, const float *W1, const float *W2,
+                      int64_t n, int D, float *Eout, void *stream);
+int yr_ngcf_dense_bwd_data(const float *dEout, const float *Eout, const float *E, const float *Z,
+                           const float *W1T, const float *W2T, int64_t n, int D,
+                           float *dZ, float *dE, void *stream);
+int yr_ngcf_dense_bwd_weight(const float *dEout, const float *Eout, const float *E, const float *Z,
+                             int64_t n, int D, float *dW1, float *dW2, void *stream);
 
 /* loss_out[0] = scale * sum(loss_partials);  if loss_accum: loss_accum[0] += same.
  * (`train_loss += loss.item()` of mf_trainer.py:114 without the per-step host sync;

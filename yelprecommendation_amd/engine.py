@@ -152,6 +152,54 @@ def bpr_mf_pull_step(U_old, U_new, I, mU, vU, mI, vI, user, pos, neg, step, lr, 
         "yr_bpr_mf_pull_step")
 
 
+def spmm_csr(graph, X, out=None, accumulate=False):
+    """Y = L X (or Y += L X) with L a :class:`yelprecommendation_amd.graph.LaplacianCSR`
+    (reference models/ngcf.py:64,67: torch.sparse.mm(L, E))."""
+    lib = _lib.load()
+    n, d = X.shape
+    if n != graph.n:
+        raise EngineError(f"X has {n} rows, the graph {graph.n}")
+    if out is None:
+        if accumulate:
+            raise EngineError("accumulate needs an output buffer")
+        out = torch.empty_like(X)
+    check(lib.yr_spmm_csr(_dev(graph.rowptr, torch.int32, "rowptr"), _dev(graph.col, torch.int32, "col"),
+                          _dev(graph.val, torch.float32, "val"), _dev(X, torch.float32, "X"),
+                          _dev(out, torch.float32, "Y"), n, d, 1 if accumulate else 0,
+                          _opt(graph.heavy_rows, torch.int32, "heavy_rows"), graph.n_heavy, graph.heavy_threshold,
+                          _stream()), "yr_spmm_csr")
+    return out
+
+
+def ngcf_dense_fwd(E, Z, W1, W2, out=None):
+    """leaky_relu((Z + E) W1^T + (E * Z) W2^T)   (reference models/ngcf.py:64-72)."""
+    lib = _lib.load()
+    n, d = E.shape
+    if out is None:
+        out = torch.empty_like(E)
+    f32 = torch.float32
+    check(lib.yr_ngcf_dense_fwd(_dev(E, f32, "E"), _dev(Z, f32, "Z"), _dev(W1, f32, "W1"), _dev(W2, f32, "W2"),
+                                n, d, _dev(out, f32, "Eout"), _stream()), "yr_ngcf_dense_fwd")
+    return out
+
+
+def ngcf_dense_bwd(dEout, Eout, E, Z, W1, W2, dE, dW1, dW2, dZ=None):
+    """Backward of :func:`ngcf_dense_fwd`: dE += ..., dW1 += ..., dW2 += ..., returns dZ."""
+    lib = _lib.load()
+    n, d = E.shape
+    f32 = torch.float32
+    if dZ is None:
+        dZ = torch.empty_like(E)
+    W1T, W2T = W1.t().contiguous(), W2.t().contiguous()      # [in, out] layout for the data-gradient GEMM
+    check(lib.yr_ngcf_dense_bwd_weight(_dev(dEout, f32, "dEout"), _dev(Eout, f32, "Eout"), _dev(E, f32, "E"),
+                                       _dev(Z, f32, "Z"), n, d, _dev(dW1, f32, "dW1"), _dev(dW2, f32, "dW2"),
+                                       _stream()), "yr_ngcf_dense_bwd_weight")
+    check(lib.yr_ngcf_dense_bwd_data(_dev(dEout, f32, "dEout"), _dev(Eout, f32, "Eout"), _dev(E, f32, "E"),
+                                     _dev(Z, f32, "Z"), _dev(W1T, f32, "W1T"), _dev(W2T, f32, "W2T"), n, d,
+                                     _dev(dZ, f32, "dZ"), _dev(dE, f32, "dE"), _stream()), "yr_ngcf_dense_bwd_data")
+    return dZ
+
+
 def loss_finalize(loss_partials, scale, loss_out=None, loss_accum=None):
     """loss_out[0] = scale * sum(partials); loss_accum[0] (float64) += the same."""
     lib = _lib.load()
