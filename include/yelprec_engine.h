@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 6
+#define YR_ENGINE_VERSION 7
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -157,6 +157,41 @@ int yr_ngcf_dense_bwd_data(const float *dEout, const float *Eout, const float *E
                            float *dZ, float *dE, void *stream);
 int yr_ngcf_dense_bwd_weight(const float *dEout, const float *Eout, const float *E, const float *Z,
                              int64_t n, int D, float *dW1, float *dW2, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * CDAE                        (reference models/cdae.py:46-52, loss.py:12-16 and their autograd)
+ *
+ * yr_gemm_f32: C[M,N] (+)= op(A)[M,K] . op(B)[K,N] on v_mfma_f32_32x32x2_f32 (exact f32), row-major,
+ *   transA/transB select A(m,k) = A[k*lda+m] / B(k,n) = B[n*ldb+k].  Plain store epilogue:
+ *   C = act(acc + bias[n]) (bias may be NULL; act 0 = identity, 1 = sigmoid).  With split_k > 1 or
+ *   accumulate != 0 the partial products are added atomically into C (caller pre-fills C; bias/act
+ *   must then be NULL/0).  Replaces nn.Linear forward (x @ W^T + b: transB = 1), its input gradient
+ *   (dy @ W) and its weight gradient (dy^T @ x: transA = 1).
+ * yr_cdae_hidden_init: zpre[b,:] = bias + V[user[b],:]   (b_h + user_nodes(user_id), cdae.py:49).
+ * yr_dropout: out = rnd >= p ? x / (1 - p) : 0, rnd uniform [0,1) supplied by the caller (nn.Dropout).
+ * yr_sigmoid / yr_sigmoid_bwd: x = sigmoid(x) in place;  g *= y (1 - y) in place.
+ * yr_colsum: out[c] (+)= sum_r X[r,c]                    (bias gradients).
+ * yr_row_scatter_add: dV[user[b],:] += G[b,:]            (embedding_dense_backward of user_nodes).
+ * yr_nsbce_fwd: NSBCELoss — positions with target + negative_mask != 0 (all positions when
+ *   negative_mask is NULL: plain nn.BCELoss); stats[0] = mean BCE (log terms clamped at -100),
+ *   stats[1] = number of selected positions.  workspace: 2 * YR_LOSS_PARTIALS floats.
+ * yr_nsbce_bwd: dpred = gout[0] * (p - t) / max((1-p) p, 1e-12) / stats[1] on selected positions, else 0.
+ * ------------------------------------------------------------------------- */
+int yr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                const float *bias, int act, int accumulate, int split_k, void *stream);
+int yr_cdae_hidden_init(float *zpre, const float *bias, const float *V, const int64_t *user,
+                        int64_t B, int H, int64_t num_users, int32_t *err_flag, void *stream);
+int yr_dropout(const float *x, const float *rnd, double p, int64_t n, float *out, void *stream);
+int yr_sigmoid(float *x, int64_t n, void *stream);
+int yr_sigmoid_bwd(float *g, const float *y, int64_t n, void *stream);
+int yr_colsum(const float *X, int64_t rows, int64_t cols, float *out, int accumulate, void *stream);
+int yr_row_scatter_add(const float *G, const int64_t *user, int64_t B, int H, int64_t num_users,
+                       float *dV, void *stream);
+int yr_nsbce_fwd(const float *pred, const float *target, const float *negative_mask, int64_t n,
+                 float *workspace, float *stats, void *stream);
+int yr_nsbce_bwd(const float *pred, const float *target, const float *negative_mask,
+                 const float *stats, const float *gout, int64_t n, float *dpred, void *stream);
 
 /* loss_out[0] = scale * sum(loss_partials);  if loss_accum: loss_accum[0] += same.
  * (`train_loss += loss.item()` of mf_trainer.py:114 without the per-step host sync;

@@ -1,0 +1,162 @@
+"""GPU parity for CDAE: the f32 MFMA GEMM in all layouts, the model's forward / NS-BCE loss / every
+parameter gradient on the golden probe batch, and a CDAETrainer run replaying the reference's
+recorded batches (users, negative masks, dropout outcomes) — tests/golden/cdae_small.npz."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cdae as ocdae
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "cdae_small.npz"))
+
+
+@pytest.mark.parametrize("tA", [False, True])
+@pytest.mark.parametrize("tB", [False, True])
+@pytest.mark.parametrize("M,N,K,split", [(1, 1, 1, 1), (32, 128, 167, 1), (70, 167, 33, 1), (24, 16, 1000, 4),
+                                         (167, 16, 24, 1), (130, 65, 64, 2)])
+def test_gemm_f32_all_layouts(device, tA, tB, M, N, K, split):
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(M + 3 * N + 7 * K)
+    A = rs.standard_normal((K, M) if tA else (M, K)).astype(np.float32)      # asymmetric operands
+    B = rs.standard_normal((N, K) if tB else (K, N)).astype(np.float32)
+    want = (A.T if tA else A) @ (B.T if tB else B)
+    dA, dB = torch.from_numpy(A).to(device), torch.from_numpy(B).to(device)
+    got = engine.gemm_f32(dA, dB, transA=tA, transB=tB, split_k=split)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    if split == 1:
+        bias = rs.standard_normal(N).astype(np.float32)
+        got = engine.gemm_f32(dA, dB, transA=tA, transB=tB, bias=torch.from_numpy(bias).to(device),
+                              act=engine.ACT_SIGMOID)
+        np.testing.assert_allclose(got.cpu().numpy(), 1 / (1 + np.exp(-(want + bias))), rtol=1e-4, atol=1e-5)
+    acc0 = rs.standard_normal((M, N)).astype(np.float32)
+    acc = torch.from_numpy(acc0.copy()).to(device)
+    engine.gemm_f32(dA, dB, transA=tA, transB=tB, out=acc, accumulate=True, split_k=split)
+    np.testing.assert_allclose(acc.cpu().numpy(), acc0 + want, rtol=1e-4, atol=1e-4)
+
+
+def _cfg(g, tmp_path, **kw):
+    from yelprecommendation_amd.utils import make_config
+    c = make_config("CDAE", hidden_size=int(g["hidden_size"]), lr=float(g["lr"]), batch_size=int(g["batch_size"]),
+                    corruption_level=float(g["corruption_level"]), neg_times=int(g["neg_times"]), loss_name="bce",
+                    device="cuda", model_dir=str(tmp_path))
+    c.update(kw)
+    return c
+
+
+def _load(model, g, prefix):
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.copy_(torch.from_numpy(g[f"{prefix}__{name.replace('.', '__')}"]))
+
+
+def test_probe_forward_loss_grads_match_reference(g, tmp_path, device):
+    from yelprecommendation_amd.loss import NSBCELoss
+    from yelprecommendation_amd.models.cdae import CDAE
+    model = CDAE(_cfg(g, tmp_path), int(g["num_items"]), int(g["num_users"]))
+    assert [n for n, _ in model.named_parameters()] == g["param_names"].tolist()
+    _load(model, g, "init")
+    model.eval()                                             # dropout off, as in the golden probe
+    u = torch.from_numpy(g["probe_user"]).to(device)
+    x = torch.from_numpy(g["probe_x"].astype(np.float32)).to(device)
+    neg = torch.from_numpy(g["probe_neg"].astype(np.float32)).to(device)
+    pred = model(u, x)
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), g["probe_pred"], rtol=1e-5, atol=1e-6)
+    loss = NSBCELoss()(pred, x, neg)
+    np.testing.assert_allclose(loss.item(), float(g["probe_loss"]), rtol=1e-5)
+    loss.backward()
+    for name, p in model.named_parameters():
+        want = g[f"grad__{name.replace('.', '__')}"]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), want, rtol=1e-3, atol=1e-7 + 1e-4 * np.abs(want).max())
+    model.check_indices()
+
+
+def test_dropout_statistics_and_eval_identity(g, tmp_path, device):
+    from yelprecommendation_amd.models.cdae import CDAE
+    model = CDAE(_cfg(g, tmp_path), int(g["num_items"]), int(g["num_users"]))
+    x = torch.ones(200, int(g["num_items"]), device=device)
+    model.train()
+    y = model.add_noise(x)
+    kept = (y != 0).float().mean().item()
+    assert abs(kept - 0.4) < 0.02 and set(torch.unique(y).tolist()) <= {0.0, 2.5}     # p = 0.6, scale 1/(1-p)
+    model.eval()
+    assert model.add_noise(x) is x
+
+
+def test_trainer_run_matches_reference(g, tmp_path, device):
+    from yelprecommendation_amd.trainers import CDAETrainer
+    t = CDAETrainer(_cfg(g, tmp_path, negative_sampling=True), int(g["num_items"]), int(g["num_users"]))
+    _load(t.model, g, "init")
+    X = g["train_input"].astype(np.float32)
+    VM = g["valid_mask"].astype(np.float32)
+    tpos = vpos = tb = vb = 0
+    for e, (ns, nv) in enumerate(zip(g["train_steps"], g["valid_steps"])):
+        batches, corrupted = [], []
+        for b in g["train_batch_sizes"][tb:tb + ns]:
+            s = slice(tpos, tpos + int(b)); tpos += int(b)
+            u = g["train_user"][s].astype(np.int64)
+            batches.append({"user_id": torch.from_numpy(u), "input_mask": torch.from_numpy(X[u]),
+                            "negative_mask": torch.from_numpy(g["train_neg"][s].astype(np.float32))})
+            corrupted.append(torch.from_numpy(g["train_keep"][s].astype(np.float32) * np.float32(2.5)))
+        tb += ns
+        it = iter(corrupted)
+        t.model.add_noise = lambda x: next(it).to(x.device)              # the reference's recorded dropout outcomes
+        train_loss = t.train(batches)
+        del t.model.add_noise
+        np.testing.assert_allclose(train_loss, g["train_epoch"][e], rtol=1e-4)
+        vbatches = []
+        for b in g["valid_batch_sizes"][vb:vb + nv]:
+            s = slice(vpos, vpos + int(b)); vpos += int(b)
+            u = g["valid_user"][s].astype(np.int64)
+            vbatches.append({"user_id": torch.from_numpy(u), "input_mask": torch.from_numpy(X[u]),
+                             "valid_mask": torch.from_numpy(VM[u]),
+                             "negative_mask": torch.from_numpy(g["valid_neg"][s].astype(np.float32))})
+        vb += nv
+        out = t.validate(vbatches)
+        np.testing.assert_allclose(out[0], g["valid_epoch"][e][0], rtol=1e-4)
+        np.testing.assert_allclose(out[1:], g["valid_epoch"][e][1:], atol=1e-3, rtol=0)
+    for name, p in t.model.named_parameters():
+        np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"final__{name.replace('.', '__')}"], rtol=1e-3, atol=1e-5)
+    # test split: evaluate() with the reference's masks
+    users = np.arange(int(g["num_users"]), dtype=np.int64)
+    tbatches = [{"user_id": torch.from_numpy(users[i:i + 32]),
+                 "input_mask": torch.from_numpy(g["test_input"][i:i + 32].astype(np.float32)),
+                 "test_mask": torch.from_numpy(g["test_mask"][i:i + 32].astype(np.float32))}
+                for i in range(0, len(users), 32)]
+    np.testing.assert_allclose(t.evaluate(tbatches), g["test_metrics"], atol=1e-3, rtol=0)
+
+
+def test_config5_shape_step_matches_oracle(device, tmp_path):
+    """BASELINE configs[4] shape in miniature (hidden 128, ragged catalogue, batch 40): one Adam step
+    against the NumPy oracle."""
+    from yelprecommendation_amd.loss import NSBCELoss
+    from yelprecommendation_amd.models.cdae import CDAE
+    from yelprecommendation_amd.optim import Adam
+    from yelprecommendation_amd.utils import make_config
+    rs = np.random.RandomState(2)
+    nu, ni, H, B = 90, 1501, 128, 40
+    cfg = make_config("CDAE", hidden_size=H, device="cuda", model_dir=str(tmp_path), lr=1e-3)
+    model = CDAE(cfg, ni, nu)
+    params = [p.detach().cpu().numpy().copy() for p in model.parameters()]
+    ref = ocdae.CDAEState(params, lr=1e-3)
+    u = rs.choice(nu, size=B, replace=False).astype(np.int64)
+    x = (rs.rand(B, ni) < 0.02).astype(np.float32)
+    keep = (rs.rand(B, ni) >= 0.6).astype(np.float32)
+    neg = ((rs.rand(B, ni) < 0.1) * (1 - x)).astype(np.float32)
+    want = float(ref.train_step(u, x * keep * np.float32(2.5), x, neg))
+    opt = Adam(model.parameters(), lr=1e-3)
+    t = lambda a: torch.from_numpy(a).to(device)
+    pred = model.encode_decode(t(u), t(x * keep * np.float32(2.5)))
+    loss = NSBCELoss()(pred, t(x), t(neg))
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    np.testing.assert_allclose(loss.item(), want, rtol=1e-5)
+    for p, r in zip(model.parameters(), ref.params):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), r, rtol=1e-3, atol=2e-6)

@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
-ENGINE_VERSION = 6
+ENGINE_VERSION = 7
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -35,6 +35,15 @@ SIGNATURES = {
     "yr_ngcf_dense_fwd": [_p, _p, _p, _p, _i64, _int, _p, _p],
     "yr_ngcf_dense_bwd_data": [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p],
     "yr_ngcf_dense_bwd_weight": [_p, _p, _p, _p, _i64, _int, _p, _p, _p],
+    "yr_gemm_f32": [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _int, _int, _int, _p],
+    "yr_cdae_hidden_init": [_p, _p, _p, _p, _i64, _int, _i64, _p, _p],
+    "yr_dropout": [_p, _p, _d, _i64, _p, _p],
+    "yr_sigmoid": [_p, _i64, _p],
+    "yr_sigmoid_bwd": [_p, _p, _i64, _p],
+    "yr_colsum": [_p, _i64, _i64, _p, _int, _p],
+    "yr_row_scatter_add": [_p, _p, _i64, _int, _i64, _p, _p],
+    "yr_nsbce_fwd": [_p, _p, _p, _i64, _p, _p, _p],
+    "yr_nsbce_bwd": [_p, _p, _p, _p, _p, _i64, _p, _p],
     "yr_loss_finalize": [_p, _f, _p, _p, _p],
     "yr_mf_scores_gemm": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _p, _p],
     "yr_topk_masked": [_p, _i64, _i64, _i64, _p, _p, _f, _int, _p, _p],

@@ -1,0 +1,320 @@
+// CDAE kernels for gfx950 (MI355X): a float32 MFMA GEMM for the encoder / decoder / their
+// gradients, and the element-wise and masked-BCE pieces around it.
+//
+// Replaces, for reference models/cdae.py:46-52 and loss.py:12-16 (+ their autograd):
+//   nn.Dropout, nn.Linear(I -> H) (+ bias, + nn.Embedding user row), sigmoid, nn.Linear(H -> I)
+//   (+ bias), sigmoid, nonzero(target + negative_mask) + binary_cross_entropy.
+// The two Linear layers and their three gradient products are GEMMs on the matrix cores
+// (v_mfma_f32_32x32x2_f32, exact f32).  Everything else is byte-bound element-wise work.
+#include "common.h"
+
+namespace yr {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// --------------------------------------------------------------------------- f32 MFMA GEMM
+// C[M, N] (+)= op(A)[M, K] . op(B)[K, N]     row-major, leading dimensions lda / ldb / ldc
+//   transA = 0: A(m, k) = A[m*lda + k]      transA = 1: A(m, k) = A[k*lda + m]
+//   transB = 0: B(k, n) = B[k*ldb + n]      transB = 1: B(k, n) = B[n*ldb + k]
+// Workgroup = 4 waves = a 64 x 64 tile of C (each wave 32 x 32), K walked in steps of 32 staged in
+// LDS as sA[m][k], sB[n][k] with pitch 33 (conflict-free for both the fill and the MFMA operand
+// reads: lane (i, h) reads row i, k = 16 h + s).  blockIdx.z splits K; with more than one split
+// (or accumulate) the epilogue adds atomically, otherwise it stores act(acc + bias[n]).
+constexpr int kGemmTile = 64;
+constexpr int kGemmK = 32;
+constexpr int kGemmPitch = kGemmK + 1;
+
+__global__ __launch_bounds__(kBlock) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                          float* __restrict__ C, int M, int N, int K, int64_t lda,
+                                                          int64_t ldb, int64_t ldc, int transA, int transB,
+                                                          const float* __restrict__ bias, int act, int atomic,
+                                                          int k_per_split) {
+  __shared__ float sA[kGemmTile * kGemmPitch];
+  __shared__ float sB[kGemmTile * kGemmPitch];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int i = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * kGemmTile, n0 = blockIdx.x * kGemmTile;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int kbeg = blockIdx.z * k_per_split;
+  const int kend = min(K, kbeg + k_per_split);
+  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k0 = kbeg; k0 < kend; k0 += kGemmK) {
+    // fill: 64 x 32 elements of each operand, 8 per thread, coalesced along the contiguous axis
+#pragma unroll
+    for (int q = 0; q < (kGemmTile * kGemmK) / kBlock; ++q) {
+      const int e = threadIdx.x + q * kBlock;
+      int m, k;
+      if (transA) { k = e / kGemmTile; m = e % kGemmTile; } else { m = e / kGemmK; k = e % kGemmK; }
+      float v = 0.0f;
+      if (m0 + m < M && k0 + k < kend)
+        v = transA ? A[(int64_t)(k0 + k) * lda + (m0 + m)] : A[(int64_t)(m0 + m) * lda + (k0 + k)];
+      sA[m * kGemmPitch + k] = v;
+      int n, kb;
+      if (transB) { n = e / kGemmK; kb = e % kGemmK; } else { kb = e / kGemmTile; n = e % kGemmTile; }
+      float w = 0.0f;
+      if (n0 + n < N && k0 + kb < kend)
+        w = transB ? B[(int64_t)(n0 + n) * ldb + (k0 + kb)] : B[(int64_t)(k0 + kb) * ldb + (n0 + n)];
+      sB[n * kGemmPitch + kb] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kGemmK / 2; ++s) {
+      const float a = sA[(wm + i) * kGemmPitch + h * (kGemmK / 2) + s];
+      const float b = sB[(wn + i) * kGemmPitch + h * (kGemmK / 2) + s];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int col = n0 + wn + i;
+  if (col < N) {
+    const float bv = (bias && !atomic) ? bias[col] : 0.0f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = m0 + wm + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (row < M) {
+        float* dst = C + (int64_t)row * ldc + col;
+        if (atomic) {
+          atomicAdd(dst, acc[reg]);
+        } else {
+          float v = acc[reg] + bv;
+          if (act == 1) v = 1.0f / (1.0f + expf(-v));
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------- element-wise pieces
+// zpre[b, :] = bias[:] + V[user[b], :]      (b_h + user_nodes(user_id), models/cdae.py:49)
+__global__ __launch_bounds__(kBlock) void cdae_hidden_init_kernel(float* __restrict__ zpre,
+                                                                  const float* __restrict__ bias,
+                                                                  const float* __restrict__ V,
+                                                                  const int64_t* __restrict__ user, int64_t B, int H,
+                                                                  int64_t num_users, int32_t* __restrict__ err_flag) {
+  const int64_t total = B * H;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+    const int64_t b = e / H;
+    const int c = (int)(e % H);
+    const int64_t u = user[b];
+    float v = bias[c];
+    if ((uint64_t)u < (uint64_t)num_users) v += V[u * H + c];
+    else if (err_flag) atomicOr(err_flag, YR_FLAG_BAD_USER);
+    zpre[e] = v;
+  }
+}
+
+// out = rnd >= p ? x / (1 - p) : 0     (nn.Dropout(p) in training mode, models/cdae.py:43-44)
+__global__ __launch_bounds__(kBlock) void dropout_kernel(const float* __restrict__ x, const float* __restrict__ rnd,
+                                                         float p, float scale, int64_t n, float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride)
+    out[e] = rnd[e] >= p ? x[e] * scale : 0.0f;
+}
+
+__global__ __launch_bounds__(kBlock) void sigmoid_kernel(float* __restrict__ x, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride)
+    x[e] = 1.0f / (1.0f + expf(-x[e]));
+}
+
+// g *= y (1 - y)        (sigmoid backward through the OUTPUT y)
+__global__ __launch_bounds__(kBlock) void sigmoid_bwd_kernel(float* __restrict__ g, const float* __restrict__ y,
+                                                             int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) g[e] *= y[e] * (1.0f - y[e]);
+}
+
+// out[c] (+)= sum_r X[r, c]        (bias gradients)
+__global__ __launch_bounds__(kBlock) void colsum_kernel(const float* __restrict__ X, int64_t rows, int64_t cols,
+                                                        float* __restrict__ out, int accumulate) {
+  const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c >= cols) return;
+  float acc = 0.0f;
+  for (int64_t r = 0; r < rows; ++r) acc += X[r * cols + c];
+  out[c] = accumulate ? out[c] + acc : acc;
+}
+
+// dV[user[b], :] += G[b, :]        (embedding_dense_backward of user_nodes)
+__global__ __launch_bounds__(kBlock) void row_scatter_add_kernel(const float* __restrict__ G,
+                                                                 const int64_t* __restrict__ user, int64_t B, int H,
+                                                                 int64_t num_users, float* __restrict__ dV) {
+  const int64_t total = B * H;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < total; e += stride) {
+    const int64_t u = user[e / H];
+    if ((uint64_t)u < (uint64_t)num_users) atomicAdd(dV + u * H + (e % H), G[e]);
+  }
+}
+
+// NS-BCE (loss.py:12-16): positions with target + negative_mask != 0 are selected;
+// stats[0] += sum of -(t max(log p, -100) + (1 - t) max(log(1 - p), -100)), stats[1] += count.
+__global__ __launch_bounds__(kBlock) void nsbce_fwd_kernel(const float* __restrict__ pred,
+                                                           const float* __restrict__ target,
+                                                           const float* __restrict__ negmask, int64_t n,
+                                                           float* __restrict__ partial_loss,
+                                                           float* __restrict__ partial_cnt) {
+  __shared__ float s_red[kWavesPerBlock];
+  float loss = 0.0f, cnt = 0.0f;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+    const float t = target[e];
+    const float m = negmask ? negmask[e] : 1.0f;
+    if (t + m != 0.0f) {
+      const float p = pred[e];
+      loss -= t * fmaxf(logf(p), -100.0f) + (1.0f - t) * fmaxf(logf(1.0f - p), -100.0f);
+      cnt += 1.0f;
+    }
+  }
+  const float tl = block_sum(loss, s_red);
+  __syncthreads();
+  const float tc = block_sum(cnt, s_red);
+  if (threadIdx.x == 0) {
+    partial_loss[blockIdx.x] = tl;
+    partial_cnt[blockIdx.x] = tc;
+  }
+}
+
+// stats[0] = mean loss, stats[1] = count     (fixed-order sums of the partials)
+__global__ __launch_bounds__(kBlock) void nsbce_finalize_kernel(const float* __restrict__ partial_loss,
+                                                                const float* __restrict__ partial_cnt, int nparts,
+                                                                float* __restrict__ stats) {
+  __shared__ float s_red[kWavesPerBlock];
+  float l = 0.0f, c = 0.0f;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) { l += partial_loss[i]; c += partial_cnt[i]; }
+  const float tl = block_sum(l, s_red);
+  __syncthreads();
+  const float tc = block_sum(c, s_red);
+  if (threadIdx.x == 0) {
+    stats[0] = tc > 0.0f ? tl / tc : 0.0f;
+    stats[1] = tc;
+  }
+}
+
+// dpred = gout * (p - t) / max((1 - p) p, 1e-12) / count on the selected positions, 0 elsewhere
+__global__ __launch_bounds__(kBlock) void nsbce_bwd_kernel(const float* __restrict__ pred,
+                                                           const float* __restrict__ target,
+                                                           const float* __restrict__ negmask,
+                                                           const float* __restrict__ stats,
+                                                           const float* __restrict__ gout, int64_t n,
+                                                           float* __restrict__ dpred) {
+  const float scale = stats[1] > 0.0f ? gout[0] / stats[1] : 0.0f;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+    const float t = target[e];
+    const float m = negmask ? negmask[e] : 1.0f;
+    float g = 0.0f;
+    if (t + m != 0.0f) {
+      const float p = pred[e];
+      g = (p - t) / fmaxf((1.0f - p) * p, 1e-12f) * scale;
+    }
+    dpred[e] = g;
+  }
+}
+
+inline int ew_grid(int64_t n) { return grid_for(n, kBlock); }
+
+}  // namespace yr
+
+using namespace yr;
+
+extern "C" int yr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                           const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act,
+                           int accumulate, int split_k, void* stream) {
+  if (M < 0 || N < 0 || K < 0 || M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) return YR_ERR_BADARG;
+  if (M == 0 || N == 0) return 0;
+  if (!A || !B || !C) return YR_ERR_BADARG;
+  if (act != 0 && act != 1) return YR_ERR_UNSUPPORTED;
+  if (split_k < 1) split_k = 1;
+  int kps = (int)((K + split_k - 1) / split_k);
+  kps = ((kps + kGemmK - 1) / kGemmK) * kGemmK;                 // whole K-steps per split
+  if (kps == 0) kps = kGemmK;
+  const int splits = (int)((K + kps - 1) / kps) > 0 ? (int)((K + kps - 1) / kps) : 1;
+  const int atomic = (splits > 1 || accumulate) ? 1 : 0;
+  if (atomic && (bias || act)) return YR_ERR_BADARG;            // fused epilogue only on a plain store
+  const dim3 grid((unsigned)((N + kGemmTile - 1) / kGemmTile), (unsigned)((M + kGemmTile - 1) / kGemmTile),
+                  (unsigned)splits);
+  if (grid.y > 65535 || grid.z > 65535) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, A, B, C, (int)M, (int)N, (int)K,
+                     lda, ldb, ldc, transA ? 1 : 0, transB ? 1 : 0, bias, act, atomic, kps);
+  return launch_status();
+}
+
+extern "C" int yr_cdae_hidden_init(float* zpre, const float* bias, const float* V, const int64_t* user, int64_t B,
+                                   int H, int64_t num_users, int32_t* err_flag, void* stream) {
+  if (B < 0 || H <= 0 || num_users <= 0) return YR_ERR_BADARG;
+  if (B == 0) return 0;
+  if (!zpre || !bias || !V || !user) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(cdae_hidden_init_kernel, dim3(ew_grid(B * H)), dim3(kBlock), 0, (hipStream_t)stream, zpre, bias,
+                     V, user, B, H, num_users, err_flag);
+  return launch_status();
+}
+
+extern "C" int yr_dropout(const float* x, const float* rnd, double p, int64_t n, float* out, void* stream) {
+  if (n < 0 || p < 0.0 || p >= 1.0) return YR_ERR_BADARG;
+  if (n == 0) return 0;
+  if (!x || !rnd || !out) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, (hipStream_t)stream, x, rnd, (float)p,
+                     (float)(1.0 / (1.0 - p)), n, out);
+  return launch_status();
+}
+
+extern "C" int yr_sigmoid(float* x, int64_t n, void* stream) {
+  if (n < 0) return YR_ERR_BADARG;
+  if (n == 0) return 0;
+  if (!x) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(sigmoid_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, (hipStream_t)stream, x, n);
+  return launch_status();
+}
+
+extern "C" int yr_sigmoid_bwd(float* g, const float* y, int64_t n, void* stream) {
+  if (n < 0) return YR_ERR_BADARG;
+  if (n == 0) return 0;
+  if (!g || !y) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, (hipStream_t)stream, g, y, n);
+  return launch_status();
+}
+
+extern "C" int yr_colsum(const float* X, int64_t rows, int64_t cols, float* out, int accumulate, void* stream) {
+  if (rows < 0 || cols < 0) return YR_ERR_BADARG;
+  if (cols == 0) return 0;
+  if (!out || (rows > 0 && !X)) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((cols + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                     (hipStream_t)stream, X, rows, cols, out, accumulate);
+  return launch_status();
+}
+
+extern "C" int yr_row_scatter_add(const float* G, const int64_t* user, int64_t B, int H, int64_t num_users, float* dV,
+                                  void* stream) {
+  if (B < 0 || H <= 0 || num_users <= 0) return YR_ERR_BADARG;
+  if (B == 0) return 0;
+  if (!G || !user || !dV) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(row_scatter_add_kernel, dim3(ew_grid(B * H)), dim3(kBlock), 0, (hipStream_t)stream, G, user, B,
+                     H, num_users, dV);
+  return launch_status();
+}
+
+extern "C" int yr_nsbce_fwd(const float* pred, const float* target, const float* negative_mask, int64_t n,
+                            float* workspace /* 2 * YR_LOSS_PARTIALS floats */, float* stats /* [2] */,
+                            void* stream) {
+  if (n < 0) return YR_ERR_BADARG;
+  if (!workspace || !stats || (n > 0 && (!pred || !target))) return YR_ERR_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = n > 0 ? ew_grid(n) : 1;
+  hipLaunchKernelGGL(nsbce_fwd_kernel, dim3(grid), dim3(kBlock), 0, s, pred, target, negative_mask, n, workspace,
+                     workspace + YR_LOSS_PARTIALS);
+  hipLaunchKernelGGL(nsbce_finalize_kernel, dim3(1), dim3(kBlock), 0, s, workspace, workspace + YR_LOSS_PARTIALS,
+                     grid, stats);
+  return launch_status();
+}
+
+extern "C" int yr_nsbce_bwd(const float* pred, const float* target, const float* negative_mask, const float* stats,
+                            const float* gout, int64_t n, float* dpred, void* stream) {
+  if (n < 0) return YR_ERR_BADARG;
+  if (n == 0) return 0;
+  if (!pred || !target || !stats || !gout || !dpred) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(nsbce_bwd_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, (hipStream_t)stream, pred, target,
+                     negative_mask, stats, gout, n, dpred);
+  return launch_status();
+}

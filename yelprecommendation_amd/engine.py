@@ -200,6 +200,102 @@ def ngcf_dense_bwd(dEout, Eout, E, Z, W1, W2, dE, dW1, dW2, dZ=None):
     return dZ
 
 
+ACT_IDENTITY, ACT_SIGMOID = 0, 1
+
+
+def gemm_f32(A, B, transA=False, transB=False, out=None, bias=None, act=ACT_IDENTITY, accumulate=False,
+             split_k=1):
+    """out (+)= op(A) @ op(B) on the f32 matrix cores.  A, B 2-D row-major f32 GPU tensors;
+    ``transA``: use A^T, ``transB``: use B^T (nn.Linear's ``x @ W^T`` is ``transB=True``)."""
+    lib = _lib.load()
+    f32 = torch.float32
+    M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
+    K2, N = (B.shape[1], B.shape[0]) if transB else (B.shape[0], B.shape[1])
+    if K != K2:
+        raise EngineError(f"inner dimensions differ: {K} vs {K2}")
+    if out is None:
+        if accumulate:
+            raise EngineError("accumulate needs an output buffer")
+        out = (torch.zeros if split_k > 1 else torch.empty)((M, N), dtype=f32, device=A.device)
+    if out.shape != (M, N) or out.stride(1) != 1:
+        raise EngineError("bad output buffer")
+    check(lib.yr_gemm_f32(1 if transA else 0, 1 if transB else 0, M, N, K, _dev(A, f32, "A"), A.stride(0),
+                          _dev(B, f32, "B"), B.stride(0), out.data_ptr(), out.stride(0),
+                          _opt(bias, f32, "bias"), int(act), 1 if accumulate else 0, int(split_k), _stream()),
+          "yr_gemm_f32")
+    return out
+
+
+def cdae_hidden_init(bias, V, user, err_flag=None):
+    """zpre[b] = bias + V[user[b]]   (reference models/cdae.py:49)."""
+    lib = _lib.load()
+    B, H = user.numel(), V.shape[1]
+    out = torch.empty((B, H), dtype=torch.float32, device=V.device)
+    check(lib.yr_cdae_hidden_init(out.data_ptr(), _dev(bias, torch.float32, "bias"), _dev(V, torch.float32, "V"),
+                                  _dev(user, torch.int64, "user"), B, H, V.shape[0],
+                                  _opt(err_flag, torch.int32, "err_flag"), _stream()), "yr_cdae_hidden_init")
+    return out
+
+
+def dropout(x, rnd, p):
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    check(lib.yr_dropout(_dev(x, torch.float32, "x"), _dev(rnd, torch.float32, "rnd"), float(p), x.numel(),
+                         out.data_ptr(), _stream()), "yr_dropout")
+    return out
+
+
+def sigmoid_(x):
+    lib = _lib.load()
+    check(lib.yr_sigmoid(_dev(x, torch.float32, "x"), x.numel(), _stream()), "yr_sigmoid")
+    return x
+
+
+def sigmoid_bwd_(g, y):
+    lib = _lib.load()
+    check(lib.yr_sigmoid_bwd(_dev(g, torch.float32, "g"), _dev(y, torch.float32, "y"), g.numel(), _stream()),
+          "yr_sigmoid_bwd")
+    return g
+
+
+def colsum(X, out=None, accumulate=False):
+    lib = _lib.load()
+    rows, cols = X.shape
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=X.device)
+    check(lib.yr_colsum(_dev(X, torch.float32, "X"), rows, cols, _dev(out, torch.float32, "out"),
+                        1 if accumulate else 0, _stream()), "yr_colsum")
+    return out
+
+
+def row_scatter_add(G, user, dV):
+    lib = _lib.load()
+    check(lib.yr_row_scatter_add(_dev(G, torch.float32, "G"), _dev(user, torch.int64, "user"), G.shape[0],
+                                 G.shape[1], dV.shape[0], _dev(dV, torch.float32, "dV"), _stream()),
+          "yr_row_scatter_add")
+
+
+def nsbce_fwd(pred, target, negative_mask):
+    """(stats, workspace): stats[0] = mean BCE over nonzero(target + negative_mask), stats[1] = count."""
+    lib = _lib.load()
+    f32 = torch.float32
+    ws = torch.empty(2 * LOSS_PARTIALS, dtype=f32, device=pred.device)
+    stats = torch.empty(2, dtype=f32, device=pred.device)
+    check(lib.yr_nsbce_fwd(_dev(pred, f32, "pred"), _dev(target, f32, "target"), _opt(negative_mask, f32, "neg"),
+                           pred.numel(), ws.data_ptr(), stats.data_ptr(), _stream()), "yr_nsbce_fwd")
+    return stats
+
+
+def nsbce_bwd(pred, target, negative_mask, stats, gout):
+    lib = _lib.load()
+    f32 = torch.float32
+    dpred = torch.empty_like(pred)
+    check(lib.yr_nsbce_bwd(_dev(pred, f32, "pred"), _dev(target, f32, "target"), _opt(negative_mask, f32, "neg"),
+                           _dev(stats, f32, "stats"), _dev(gout, f32, "gout"), pred.numel(), dpred.data_ptr(),
+                           _stream()), "yr_nsbce_bwd")
+    return dpred
+
+
 def loss_finalize(loss_partials, scale, loss_out=None, loss_accum=None):
     """loss_out[0] = scale * sum(partials); loss_accum[0] (float64) += the same."""
     lib = _lib.load()

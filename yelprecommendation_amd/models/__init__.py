@@ -1,5 +1,6 @@
 from .base_model import BaseModel
+from .cdae import CDAE
 from .mf import MatrixFactorization
 from .ngcf import NGCF
 
-__all__ = ["BaseModel", "MatrixFactorization", "NGCF"]
+__all__ = ["BaseModel", "CDAE", "MatrixFactorization", "NGCF"]

@@ -1,0 +1,115 @@
+"""CDAE trainer — drop-in for reference trainers/cdae_trainer.py:20-144.
+
+Same constructor ``CDAETrainer(cfg, num_items, num_users)`` and the same contract:
+``train`` returns the sum of per-batch losses, ``validate`` returns
+``(loss, precision, recall, map, ndcg)``, ``evaluate`` returns the four metrics.  Seen items are
+masked the reference's way — scores multiplied by ``logical_not(input_mask)`` (-> 0, valid
+because sigmoid > 0; trainers/cdae_trainer.py:132) — through the masked top-k kernel with
+mask value 0.
+"""
+import numpy as np
+import torch
+
+from .. import engine
+from ..loss import BCELoss, NSBCELoss
+from ..metric import ranking_metrics
+from ..models.cdae import CDAE
+from ..utils import log_metric, logger
+from .base_trainer import BaseTrainer
+
+
+class CDAETrainer(BaseTrainer):
+    def __init__(self, cfg, num_items: int, num_users: int) -> None:
+        super().__init__(cfg)
+        self.model = CDAE(self.cfg, num_items, num_users)
+        self.optimizer = self._optimizer(self.cfg.optimizer, self.model, self.cfg.lr)
+        self.loss = self._loss()
+        self._loss_accum = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self._partials = torch.zeros(engine.LOSS_PARTIALS, dtype=torch.float32, device=self.device)
+
+    def _loss(self):
+        # reference cdae_trainer.py:26-33
+        if self.cfg.loss_name.lower() == 'bce' and self.cfg.negative_sampling:
+            return NSBCELoss()
+        elif self.cfg.loss_name.lower() == 'bce' and not self.cfg.negative_sampling:
+            return BCELoss()
+        else:
+            logger.error(f"Loss Not Exists: {self.cfg.loss_name} when negative_sampling == {self.cfg.negative_sampling}")
+            raise NotImplementedError(f"Loss Not Exists: {self.cfg.loss_name}")
+
+    def _accumulate(self, loss):
+        self._partials[:1].copy_(loss.detach().reshape(1))
+        engine.loss_finalize(self._partials, 1.0, None, self._loss_accum)
+
+    def train(self, train_dataloader) -> float:
+        # reference cdae_trainer.py:36-54
+        self.model.train()
+        self._loss_accum.zero_()
+        for data in train_dataloader:
+            user_id, input_mask = data['user_id'].to(self.device), data['input_mask'].to(self.device)
+            pred = self.model(user_id, input_mask)
+            self.optimizer.zero_grad()
+            if self.cfg.negative_sampling:
+                negative_mask = data['negative_mask'].to(self.device)
+                loss = self.loss(pred, input_mask, negative_mask)
+            else:
+                loss = self.loss(pred, input_mask)
+            loss.backward()
+            self.optimizer.step()
+            self._accumulate(loss)
+        self.model.check_indices()
+        return float(self._loss_accum.item())
+
+    def validate(self, valid_dataloader):
+        # reference cdae_trainer.py:56-88
+        self.model.eval()
+        self._loss_accum.zero_()
+        actual, predicted = [], []
+        with torch.no_grad():
+            for data in valid_dataloader:
+                user_id, input_mask = data['user_id'].to(self.device), data['input_mask'].to(self.device)
+                valid_mask = data['valid_mask'].to(self.device)
+                pred = self.model(user_id, input_mask)
+                target = input_mask.clone()                       # input_mask.add(valid_mask), cdae_trainer.py:67
+                engine.sgd_dense(target, valid_mask.contiguous(), -1.0)
+                if self.cfg.negative_sampling:
+                    loss = self.loss(pred, target, data['negative_mask'].to(self.device))
+                else:
+                    loss = self.loss(pred, target)
+                self._accumulate(loss)
+                batch_actual, batch_predicted = self._generate_target_and_top_k_recommendation(pred, valid_mask, input_mask)
+                actual.extend(batch_actual)
+                predicted.extend(batch_predicted)
+        predicted = np.concatenate(predicted, axis=0)
+        p, r, m, n = ranking_metrics(actual, predicted.tolist(), self.cfg.top_n)
+        return (float(self._loss_accum.item()), p, r, m, n)
+
+    @log_metric
+    def evaluate(self, test_dataloader):
+        # reference cdae_trainer.py:90-121
+        self.model.eval()
+        actual, predicted = [], []
+        with torch.no_grad():
+            for data in test_dataloader:
+                input_mask, user_id, test_mask = data['input_mask'].to(self.device), \
+                    data['user_id'].to(self.device), data['test_mask'].to(self.device)
+                pred = self.model(user_id, input_mask)
+                batch_actual, batch_predicted = self._generate_target_and_top_k_recommendation(pred, test_mask, input_mask)
+                actual.extend(batch_actual)
+                predicted.extend(batch_predicted)
+        predicted = np.concatenate(predicted, axis=0)
+        p, r, m, n = ranking_metrics(actual, predicted.tolist(), self.cfg.top_n)
+        logger.info(f"[Trainer] Test > precision@{self.cfg.top_n} : {p:.4f} / Recall@{self.cfg.top_n}: {r:.4f} / "
+                    f"MAP@{self.cfg.top_n}: {m:.4f} / NDCG@{self.cfg.top_n}: {n:.4f}")
+        return (p, r, m, n)
+
+    def _generate_target_and_top_k_recommendation(self, pred, actual_mask, pred_mask):
+        # reference cdae_trainer.py:123-144
+        actual = [np.nonzero(row)[0] for row in actual_mask.cpu().numpy()]
+        # CSR of the seen items per row (index bookkeeping only), masked scores become 0 in the kernel
+        nz = pred_mask.nonzero()
+        counts = torch.bincount(nz[:, 0], minlength=pred_mask.shape[0])
+        ptr = torch.zeros(pred_mask.shape[0] + 1, dtype=torch.int64, device=pred.device)
+        ptr[1:] = torch.cumsum(counts, 0)
+        top = engine.topk_masked(pred.detach().contiguous(), ptr, nz[:, 1].contiguous(), self.cfg.top_n, mask_value=0.0)
+        return actual, [top.cpu().numpy()]
