@@ -132,3 +132,86 @@ def test_best_epoch_is_argmin_valid_loss(g):
     ref = g["U_final"] if best == len(g["valid_epoch_loss"]) - 1 else None
     if ref is not None:
         np.testing.assert_array_equal(g["U_best"], ref)
+
+
+# --------------------------------------------------------------------------- NGCF oracle
+def test_ngcf_oracle_matches_reference(golden_dir):
+    import scipy.sparse as sp
+    from oracle import ngcf as on
+    g = np.load(os.path.join(golden_dir, "ngcf_tiny.npz"))
+    U, I, K = int(g["num_users"]), int(g["num_items"]), int(g["num_orders"])
+    L = on.laplacian_csr(g["tsv_user"], g["tsv_item"], g["tsv_rating"], U, I)
+    Lref = sp.csr_matrix((g["lap_val"], (g["lap_row"], g["lap_col"])), shape=(U + I, U + I))
+    assert L.nnz == Lref.nnz and abs(L - Lref).max() <= 1e-7 and abs(L - L.T).max() <= 1e-6
+    E0 = g["init__embedding__weight"]
+    W1 = [g[f"init__W1__{k}__weight"] for k in range(K)]
+    W2 = [g[f"init__W2__{k}__weight"] for k in range(K)]
+    e1, _ = on.propagate(E0, W1[0], W2[0], Lref)
+    np.testing.assert_allclose(e1, g["probe_layer1"], rtol=1e-5, atol=1e-6)
+    pos, neg = on.bpr_forward(E0, W1, W2, Lref, U, g["probe_u"], g["probe_p"], g["probe_n"])
+    np.testing.assert_allclose(pos, g["probe_pos"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(neg, g["probe_neg"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(on.forward(E0, W1, W2, Lref, U, g["probe_u"], g["probe_p"]), g["probe_forward"],
+                               rtol=1e-5, atol=1e-5)
+    loss, dE, dW1, dW2 = on.loss_and_grads(E0, W1, W2, Lref, U, g["probe_u"], g["probe_p"], g["probe_n"])
+    np.testing.assert_allclose(loss, float(g["probe_loss"]), rtol=1e-6)
+    np.testing.assert_allclose(dE, g["grad__embedding__weight"], rtol=1e-4, atol=1e-7)
+    for k in range(K):
+        np.testing.assert_allclose(dW1[k], g[f"grad__W1__{k}__weight"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(dW2[k], g[f"grad__W2__{k}__weight"], rtol=1e-4, atol=1e-6)
+    st = on.NGCFState(E0, W1, W2, Lref, U, lr=float(g["lr"]))
+    pos_, bp = 0, 0
+    for e, ns in enumerate(g["train_steps"]):
+        tot = 0.0
+        for b in g["train_batch_sizes"][bp:bp + ns]:
+            s = slice(pos_, pos_ + int(b)); pos_ += int(b)
+            tot += float(st.train_step(*(g[k][s].astype(np.int64) for k in ("train_u", "train_p", "train_n"))))
+        bp += ns
+        np.testing.assert_allclose(tot, g["train_epoch_loss"][e], rtol=1e-6)
+    np.testing.assert_allclose(st.E, g["final__embedding__weight"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(st.W2[1], g["final__W2__1__weight"], rtol=0, atol=2e-6)
+
+
+# --------------------------------------------------------------------------- CDAE oracle
+def test_cdae_oracle_matches_reference(golden_dir):
+    from oracle import cdae as oc
+    g = np.load(os.path.join(golden_dir, "cdae_small.npz"))
+    names = [n.replace(".", "__") for n in g["param_names"]]
+    assert names == ["hidden_layer__weight", "hidden_layer__bias", "user_nodes__weight",
+                     "output_layer__weight", "output_layer__bias"]
+    init = [g["init__" + n] for n in names]
+    x = g["probe_x"].astype(np.float32)
+    y, _ = oc.forward(init, g["probe_user"], x)
+    np.testing.assert_allclose(y, g["probe_pred"], rtol=1e-6, atol=1e-6)
+    loss, grads = oc.loss_and_grads(init, g["probe_user"], x, x, g["probe_neg"].astype(np.float32))
+    np.testing.assert_allclose(loss, float(g["probe_loss"]), rtol=1e-6)
+    for n, gr in zip(names, grads):
+        np.testing.assert_allclose(gr, g["grad__" + n], rtol=1e-4, atol=1e-8)
+    st = oc.CDAEState(init, lr=float(g["lr"]))
+    X, VM = g["train_input"].astype(np.float32), g["valid_mask"].astype(np.float32)
+    pos = bp = vpos = vbp = 0
+    for e, (ns, nv) in enumerate(zip(g["train_steps"], g["valid_steps"])):
+        tot = 0.0
+        for b in g["train_batch_sizes"][bp:bp + ns]:
+            s = slice(pos, pos + int(b)); pos += int(b)
+            u = g["train_user"][s].astype(np.int64)
+            tot += float(st.train_step(u, g["train_keep"][s].astype(np.float32) * np.float32(2.5), X[u],
+                                       g["train_neg"][s].astype(np.float32)))
+        bp += ns
+        np.testing.assert_allclose(tot, g["train_epoch"][e], rtol=1e-6)
+        vt, preds, acts = 0.0, [], []
+        for b in g["valid_batch_sizes"][vbp:vbp + nv]:
+            s = slice(vpos, vpos + int(b)); vpos += int(b)
+            u = g["valid_user"][s].astype(np.int64)
+            p = st.predict(u, X[u])
+            vt += float(oc.nsbce_loss(p, X[u] + VM[u], g["valid_neg"][s].astype(np.float32))[0])
+            preds.append(oc.top_k_multiply_mask(p, X[u], 10))
+            acts += [np.nonzero(VM[uu])[0] for uu in u]
+        vbp += nv
+        pred = np.concatenate(preds)
+        np.testing.assert_allclose(vt, g["valid_epoch"][e][0], rtol=1e-6)
+        m = (ometric.precision_at_k(acts, pred, 10), ometric.recall_at_k(acts, pred, 10),
+             ometric.map_at_k(acts, pred, 10), ometric.ndcg_at_k(acts, pred, 10))
+        np.testing.assert_allclose(m, g["valid_epoch"][e][1:], rtol=1e-9, atol=1e-12)
+    for n, p in zip(names, st.params):
+        np.testing.assert_allclose(p, g["final__" + n], rtol=0, atol=2e-6)
