@@ -135,8 +135,21 @@ def main():
     dom = max(kt, key=lambda k: kt[k][0] * kt[k][1])
     avg_us, launches, alg_bytes = kt[dom]
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+    # HBM-side traffic per step from rocprofv3 PMC passes of this same command (FETCH_SIZE doubled
+    # as MI355X_MICROARCH.md prescribes, + WRITE_SIZE), committed under profiles/ by
+    # scripts/pmc_traffic.py; null when no such measurement is in the tree.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if world == 1 and os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("batch_per_gpu") == B and tj.get("step_impl") == step.impl:
+                traffic = tj["hbm_bytes_per_step"]
+        except (ValueError, KeyError):
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom + " (launch group: " + step.launches + ")",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_kernel_us": round(avg_us, 2), "launches": launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernels_us": {k: round(v[0], 2) for k, v in kt.items()}}

@@ -44,6 +44,8 @@ class BPRMFStep:
         if impl not in IMPL_NAMES:
             raise ValueError(f"impl must be one of {list(IMPL_NAMES)}")
         self.impl_key, self.impl = impl, IMPL_NAMES[impl]
+        self.launches = ("part_count, part_scan, part_scatter, bucket_sort, pull_rows<user>, pull_rows<item>"
+                         if impl == "pull" else "bpr_fwd_bwd, adam_dense x2")
         self.heavy_threshold = heavy_threshold
         self.U, self.I = U, I
         self._U_alt = torch.empty_like(U) if impl == "pull" else None
