@@ -18,16 +18,18 @@
 //   level 1  rows are cut into buckets of 64 consecutive rows.  A workgroup histograms its tile
 //            of 8192 triplets per bucket in LDS (integer LDS atomics), reserves a range in each
 //            bucket with ONE global atomic per (workgroup, bucket), and scatters
-//              rec1[slot] = {pos, neg | local_user_row << 24, slot_pos, slot_neg}   by user bucket
-//              occ1[slot] = user | local_item_row << 24  (one per pos/neg occurrence) by item bucket
+//              rec1[slot] = {pos, neg | local_user_row << 24, triplet id b}          by user bucket
+//              occ1[slot] = {user | local_item_row << 24, b | sign}  (one per pos/neg occurrence)
+//                                                                                    by item bucket
 //   level 2  one workgroup per bucket counting-sorts the bucket's records by local row in LDS and
-//            writes rec2 / occ2 = {user, level-1 slot} in row order plus the row offsets
+//            writes rec2 / occ2 in row order plus the row offsets
 //            offU / offI; rows with more than `heavy` contributions go on a heavy list (a whole
 //            workgroup sums such a row, one wave every other row).
 //   user pass    row u: x_b = U[u].(I[p_b]-I[n_b]); loss += softplus(-x_b);
 //                g_b = -sigmoid(-x_b)/B; acc += g_b (I[p_b]-I[n_b]);
-//                occ_g[slot_pos] = g_b; occ_g[slot_neg] = -g_b;  U_new[u] = Adam(U[u], acc)
-//   item pass    row i: acc = sum_j occ_g[occ2[j].slot] * U[occ2[j].user];  I[i] = Adam(I[i], acc)
+//                coeff[b] = g_b (4 B per triplet, stays in L2);  U_new[u] = Adam(U[u], acc)
+//   permute      g_item[j] = (+/-) coeff[b_j] for every occurrence j in item order (plain gather)
+//   item pass    row i: acc = sum_j g_item[j] * U[user_j];  I[i] = Adam(I[i], acc)
 // The user table is double-buffered (U -> U_new) because the item pass needs the OLD user rows;
 // the item table is updated in place (a row is read only by its own wave).
 //
@@ -41,7 +43,10 @@ namespace yr {
 constexpr int kBucketRows = 64;                 // rows per bucket (power of two)
 constexpr int kBucketShift = 6;
 constexpr int kPartThreads = 1024;              // partition workgroup
-constexpr int kPartPerThread = 8;
+#ifndef YR_PART_PER_THREAD
+#define YR_PART_PER_THREAD 8
+#endif
+constexpr int kPartPerThread = YR_PART_PER_THREAD;
 constexpr int kPartTile = kPartThreads * kPartPerThread;   // triplets per partition workgroup
 constexpr int kLocalShift = 24;                 // ids < 2^24 share a word with the local row
 constexpr int kIdMask = (1 << kLocalShift) - 1;
@@ -113,13 +118,16 @@ __global__ __launch_bounds__(kPartThreads) void part_count_kernel(const int64_t*
                                                                   const int64_t* __restrict__ neg, int64_t B,
                                                                   int64_t nU, int64_t nI, int nbU, int nb_all,
                                                                   int32_t* __restrict__ cnt_all,
+                                                                  int32_t* __restrict__ cnt_tile,
                                                                   int32_t* __restrict__ err_flag) {
   extern __shared__ int32_t s_cnt[];
   Tile t;
   const int bad = load_tile(t, user, pos, neg, B, nU, nI);
   tile_histogram(t, s_cnt, nbU, nb_all);
+  int32_t* mine = cnt_tile + (int64_t)blockIdx.x * nb_all;     // this tile's counts, reused by the scatter pass
   for (int i = threadIdx.x; i < nb_all; i += kPartThreads) {
     const int c = s_cnt[i];
+    mine[i] = c;
     if (c) atomicAdd(&cnt_all[i], c);
   }
   if (bad && err_flag) atomicOr(err_flag, bad);
@@ -171,16 +179,17 @@ __global__ __launch_bounds__(kPartThreads) void part_scatter_kernel(const int64_
                                                                     const int64_t* __restrict__ neg, int64_t B,
                                                                     int64_t nU, int64_t nI, int nbU, int nb_all,
                                                                     int32_t* __restrict__ cur_all,
+                                                                    const int32_t* __restrict__ cnt_tile,
                                                                     int4* __restrict__ user_rec,
-                                                                    int32_t* __restrict__ occ_rec) {
+                                                                    int2* __restrict__ occ_rec) {
   extern __shared__ int32_t s_mem[];
-  int32_t* s_cnt = s_mem;             // [nb_all] counts, then running ranks
+  int32_t* s_cnt = s_mem;             // [nb_all] running ranks
   int32_t* s_start = s_mem + nb_all;  // [nb_all] reserved start per bucket
   Tile t;
   load_tile(t, user, pos, neg, B, nU, nI);
-  tile_histogram(t, s_cnt, nbU, nb_all);
+  const int32_t* mine = cnt_tile + (int64_t)blockIdx.x * nb_all;   // counted by part_count_kernel
   for (int i = threadIdx.x; i < nb_all; i += kPartThreads) {
-    const int c = s_cnt[i];
+    const int c = mine[i];
     s_start[i] = c ? atomicAdd(&cur_all[i], c) : 0;
     s_cnt[i] = 0;
   }
@@ -193,16 +202,20 @@ __global__ __launch_bounds__(kPartThreads) void part_scatter_kernel(const int64_
       const int su = s_start[bu] + atomicAdd(&s_cnt[bu], 1);
       const int sp = s_start[bp] + atomicAdd(&s_cnt[bp], 1);
       const int sn = s_start[bn] + atomicAdd(&s_cnt[bn], 1);
-      user_rec[su] = make_int4(t.p[k], t.n[k] | ((t.u[k] & (kBucketRows - 1)) << kLocalShift), sp, sn);
-      occ_rec[sp] = t.u[k] | ((t.p[k] & (kBucketRows - 1)) << kLocalShift);
-      occ_rec[sn] = t.u[k] | ((t.n[k] & (kBucketRows - 1)) << kLocalShift);
+      const int b = (int)(blockIdx.x * kPartTile + threadIdx.x + k * kPartThreads);   // triplet id
+      user_rec[su] = make_int4(t.p[k], t.n[k] | ((t.u[k] & (kBucketRows - 1)) << kLocalShift), b, 0);
+      occ_rec[sp] = make_int2(t.u[k] | ((t.p[k] & (kBucketRows - 1)) << kLocalShift), b);
+      occ_rec[sn] = make_int2(t.u[k] | ((t.n[k] & (kBucketRows - 1)) << kLocalShift), b | (int)0x80000000);
     }
   }
 }
 
 // --------------------------------------------------------------------------- level-2 sort
 // One workgroup per bucket: counting sort of the bucket's records by local row.
-constexpr int kSortThreads = 256;
+#ifndef YR_SORT_THREADS
+#define YR_SORT_THREADS 1024
+#endif
+constexpr int kSortThreads = YR_SORT_THREADS;
 
 struct SortSide {
   const int32_t* base;     // [buckets + 1]
@@ -212,10 +225,11 @@ struct SortSide {
   int buckets, rows;
 };
 
-// blocks [0, U.buckets) sort user buckets (rec1 -> rec2), the rest item buckets (occ1 -> occ2)
+// One workgroup per bucket: blocks [0, su.buckets) sort user buckets (rec1 -> rec2), the others item
+// buckets (occ1 -> occ2), both by local row with LDS rank atomics.
 __global__ __launch_bounds__(kSortThreads) void bucket_sort_kernel(SortSide su, SortSide si,
                                                                    const int4* __restrict__ rec1,
-                                                                   const int32_t* __restrict__ occ1,
+                                                                   const int2* __restrict__ occ1,
                                                                    int4* __restrict__ rec2, int2* __restrict__ occ2,
                                                                    int heavy_t) {
   __shared__ int s_cnt[kBucketRows];
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(kSortThreads) void bucket_sort_kernel(SortSide su, 
   if (threadIdx.x < kBucketRows) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   for (int i = lo + threadIdx.x; i < hi; i += kSortThreads) {
-    const uint32_t w = user ? (uint32_t)rec1[i].y : (uint32_t)occ1[i];
+    const uint32_t w = user ? (uint32_t)rec1[i].y : (uint32_t)occ1[i].x;
     atomicAdd(&s_cnt[w >> kLocalShift], 1);
   }
   __syncthreads();
@@ -257,8 +271,10 @@ __global__ __launch_bounds__(kSortThreads) void bucket_sort_kernel(SortSide su, 
       r.y &= kIdMask;
       rec2[atomicAdd(&s_start[local], 1)] = r;
     } else {
-      const uint32_t w = (uint32_t)occ1[i];
-      occ2[atomicAdd(&s_start[w >> kLocalShift], 1)] = make_int2((int)(w & kIdMask), i);
+      int2 o = occ1[i];
+      const int local = (uint32_t)o.x >> kLocalShift;
+      o.x &= kIdMask;
+      occ2[atomicAdd(&s_start[local], 1)] = o;
     }
   }
 }
@@ -272,9 +288,9 @@ struct RowPassArgs {
   float* v;
   float* grad_out;           // item pass, FUSE_ADAM = false: dense gradient rows instead of Adam
   const int32_t* off;        // [rows + 1] contribution range of each row
-  const int4* rec;           // user pass: {pos, neg, slot_pos, slot_neg} in user order
-  const int2* occ;           // item pass: {user, level-1 slot} in item order
-  float* occ_g;              // [2B] by level-1 slot: user pass writes, item pass reads
+  const int4* rec;           // user pass: {pos, neg, triplet id, -} in user order
+  const int2* occ;           // item pass: {user, triplet id | sign bit (neg occurrence)} in item order
+  float* coeff;              // user pass: [B] g_b by triplet id (written); item pass: [2B] signed g in item order
   const int32_t* heavy;      // heavy-row list and its length
   const int32_t* nheavy;
   float* loss_partials;      // user pass
@@ -291,83 +307,59 @@ struct PullGeom {
   static constexpr int GPW = kWave / LPR;      // contributions per wave pass
 };
 
-// contributions in flight per lane group: the user pass is VALU-heavier and holds two rows per
-// contribution, the item pass is pure latency
-template <bool USER>
-struct PullUnroll {
-  static constexpr int N = USER ? 2 : 4;
-};
+// contributions in flight per lane group and pass
+constexpr int kUserUnroll = 2;   // VALU-heavier, two rows per contribution
+constexpr int kItemUnroll = 4;   // pure latency: rows of TWO passes are kept in flight
 
-// The index words of one contribution: user pass {pos, neg, slot_pos, slot_neg}; item pass {user, slot}.
-template <bool USER>
-__device__ __forceinline__ int4 load_index(const RowPassArgs& a, int idx, bool valid) {
-  if (!valid) return make_int4(0, 0, 0, 0);
-  if (USER) return a.rec[idx];
-  const int2 o = a.occ[idx];
-  return make_int4(o.x, o.y, 0, 0);
-}
-
-// Accumulate the contributions [lo, hi) of one row, visiting indices base + first + k*step.
-// Adds into this lane group's partial gradient (float4 at column 4*l) and loss.  Software
-// pipelined: the index words of the NEXT pass are loaded before the rows of this one are used,
-// so the dependent chain index -> row never leaves the wave without loads in flight.
-template <int D, bool USER>
-__device__ __forceinline__ void pull_accumulate(const RowPassArgs& a, int lo, int hi, int first, int step,
-                                                const float4& own, int l, float4& acc, float& loss) {
+// User pass: accumulate the contributions [lo, hi) of one user row, visiting indices
+// base + first + k*step.  Adds into this lane group's partial gradient (float4 at column 4*l) and
+// loss.  Software pipelined: the index words of the NEXT pass are loaded before the rows of this
+// one are used, so the dependent chain index -> row never leaves the wave without loads in flight.
+template <int D>
+__device__ __forceinline__ void pull_accumulate_user(const RowPassArgs& a, int lo, int hi, int first, int step,
+                                                     const float4& own, int l, float4& acc, float& loss) {
   using G = PullGeom<D>;
-  constexpr int N = PullUnroll<USER>::N;
+  constexpr int N = kUserUnroll;
   int4 cur[N], nxt[N];
   bool cur_valid[N];
 #pragma unroll
   for (int q = 0; q < N; ++q) {
     const int idx = lo + first + q * step;
     cur_valid[q] = idx < hi;
-    cur[q] = load_index<USER>(a, idx, cur_valid[q]);
+    cur[q] = cur_valid[q] ? a.rec[idx] : make_int4(0, 0, 0, 0);
   }
   // uniform trip count across the wave / workgroup: the start is common, `first` only offsets idx
   for (int base = lo; base < hi; base += step * N) {
     float4 r0[N], r1[N];
-    float g[N];
 #pragma unroll
     for (int q = 0; q < N; ++q) {
-      if (USER) {
-        r0[q] = ld4(a.other + (int64_t)cur[q].x * D + 4 * l);
-        r1[q] = ld4(a.other + (int64_t)cur[q].y * D + 4 * l);
-      } else {
-        g[q] = cur_valid[q] ? a.occ_g[cur[q].y] : 0.0f;
-        r0[q] = ld4(a.other + (int64_t)cur[q].x * D + 4 * l);
-      }
+      r0[q] = ld4(a.other + (int64_t)cur[q].x * D + 4 * l);
+      r1[q] = ld4(a.other + (int64_t)cur[q].y * D + 4 * l);
     }
     bool nxt_valid[N];
 #pragma unroll
     for (int q = 0; q < N; ++q) {
       const int idx = base + step * N + first + q * step;
       nxt_valid[q] = idx < hi;
-      nxt[q] = load_index<USER>(a, idx, nxt_valid[q]);
+      nxt[q] = nxt_valid[q] ? a.rec[idx] : make_int4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < N; ++q) {
-      if (USER) {
-        float4 d;
-        d.x = r0[q].x - r1[q].x; d.y = r0[q].y - r1[q].y; d.z = r0[q].z - r1[q].z; d.w = r0[q].w - r1[q].w;
-        float part = own.x * d.x;
-        part = fmaf(own.y, d.y, part);
-        part = fmaf(own.z, d.z, part);
-        part = fmaf(own.w, d.w, part);
-        const float x = group_sum_dpp<G::LPR>(part);
-        float sp, sg;
-        bpr_terms(x, sp, sg);
-        const float gg = cur_valid[q] ? -sg * a.inv_batch : 0.0f;
-        acc.x = fmaf(gg, d.x, acc.x); acc.y = fmaf(gg, d.y, acc.y);
-        acc.z = fmaf(gg, d.z, acc.z); acc.w = fmaf(gg, d.w, acc.w);
-        if (cur_valid[q] && l == 0) {
-          a.occ_g[cur[q].z] = gg;
-          a.occ_g[cur[q].w] = -gg;
-          loss += sp;
-        }
-      } else {
-        acc.x = fmaf(g[q], r0[q].x, acc.x); acc.y = fmaf(g[q], r0[q].y, acc.y);
-        acc.z = fmaf(g[q], r0[q].z, acc.z); acc.w = fmaf(g[q], r0[q].w, acc.w);
+      float4 d;
+      d.x = r0[q].x - r1[q].x; d.y = r0[q].y - r1[q].y; d.z = r0[q].z - r1[q].z; d.w = r0[q].w - r1[q].w;
+      float part = own.x * d.x;
+      part = fmaf(own.y, d.y, part);
+      part = fmaf(own.z, d.z, part);
+      part = fmaf(own.w, d.w, part);
+      const float x = group_sum_dpp<G::LPR>(part);
+      float sp, sg;
+      bpr_terms(x, sp, sg);
+      const float gg = cur_valid[q] ? -sg * a.inv_batch : 0.0f;
+      acc.x = fmaf(gg, d.x, acc.x); acc.y = fmaf(gg, d.y, acc.y);
+      acc.z = fmaf(gg, d.z, acc.z); acc.w = fmaf(gg, d.w, acc.w);
+      if (cur_valid[q] && l == 0) {
+        a.coeff[cur[q].z] = gg;                 // one hand-off word per triplet; the item side applies the sign
+        loss += sp;
       }
     }
 #pragma unroll
@@ -376,6 +368,67 @@ __device__ __forceinline__ void pull_accumulate(const RowPassArgs& a, int lo, in
       cur_valid[q] = nxt_valid[q];
     }
   }
+}
+
+// Item pass: acc += sum over [lo, hi) of (+/-) g_b * U[user], {user, b | sign} read contiguously from
+// `occ`, g_b from the per-triplet coefficient array.  Two passes of rows are in flight: the rows
+// (and coefficients) of pass k+1 are requested before those of pass k are consumed, and the index
+// words of pass k+2 before that.
+template <int D>
+__device__ __forceinline__ void pull_accumulate_item(const RowPassArgs& a, int lo, int hi, int first, int step,
+                                                     int l, float4& acc) {
+  constexpr int N = kItemUnroll;
+  int cur[N], nxt[N];                             // user ids; padding = user 0 with g = 0
+  float4 rcur[N];
+  float gcur[N], gnx[N];
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    const int idx = lo + first + q * step;
+    cur[q] = idx < hi ? a.occ[idx].x : 0;
+    gcur[q] = idx < hi ? a.coeff[idx] : 0.0f;
+  }
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    const int idx = lo + step * N + first + q * step;
+    nxt[q] = idx < hi ? a.occ[idx].x : 0;
+    gnx[q] = idx < hi ? a.coeff[idx] : 0.0f;
+  }
+#pragma unroll
+  for (int q = 0; q < N; ++q) rcur[q] = ld4(a.other + (int64_t)cur[q] * D + 4 * l);
+  for (int base = lo; base < hi; base += step * N) {
+    float4 rnxt[N];
+    int nn[N];
+    float gn[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) rnxt[q] = ld4(a.other + (int64_t)nxt[q] * D + 4 * l);
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      const int idx = base + 2 * step * N + first + q * step;
+      nn[q] = idx < hi ? a.occ[idx].x : 0;
+      gn[q] = idx < hi ? a.coeff[idx] : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      const float g = gcur[q];
+      acc.x = fmaf(g, rcur[q].x, acc.x); acc.y = fmaf(g, rcur[q].y, acc.y);
+      acc.z = fmaf(g, rcur[q].z, acc.z); acc.w = fmaf(g, rcur[q].w, acc.w);
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      cur[q] = nxt[q];
+      rcur[q] = rnxt[q];
+      gcur[q] = gnx[q];
+      nxt[q] = nn[q];
+      gnx[q] = gn[q];
+    }
+  }
+}
+
+template <int D, bool USER>
+__device__ __forceinline__ void pull_accumulate(const RowPassArgs& a, int lo, int hi, int first, int step,
+                                                const float4& own, int l, float4& acc, float& loss) {
+  if (USER) pull_accumulate_user<D>(a, lo, hi, first, step, own, l, acc, loss);
+  else pull_accumulate_item<D>(a, lo, hi, first, step, l, acc);
 }
 
 // sum a float4 over the lane groups of a wave (lanes with equal l)
@@ -459,6 +512,24 @@ __global__ __launch_bounds__(kBlock) void pull_rows_kernel(RowPassArgs a) {
   }
 }
 
+// g_item[j] = (+/-) coeff[b_j] for every occurrence j in item order: a plain massively parallel
+// gather (coalesced index reads and stores) so that the item pass streams {user, g} contiguously
+// instead of chasing the per-triplet coefficient from inside its latency-bound row loop.
+__global__ __launch_bounds__(kBlock) void pull_permute_coeff_kernel(const int2* __restrict__ occ,
+                                                                    const float* __restrict__ coeff,
+                                                                    const int32_t* __restrict__ n_occ,
+                                                                    float* __restrict__ g_item) {
+  // only the occurrences of VALID triplets exist (out-of-range triplets were skipped by the
+  // partition): their number is the end of the last item bucket, not 2 * B
+  const int64_t n = n_occ[0];
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x; j < n; j += stride) {
+    const int b = occ[j].y;
+    const float g = coeff[b & 0x7fffffff];
+    g_item[j] = b < 0 ? -g : g;
+  }
+}
+
 __global__ void pull_clear_partials_kernel(float* p, int from, int to) {
   const int i = from + blockIdx.x * blockDim.x + threadIdx.x;
   if (i < to) p[i] = 0.0f;
@@ -466,8 +537,9 @@ __global__ void pull_clear_partials_kernel(float* p, int from, int to) {
 
 // workspace carve-up (all 16-byte aligned)
 struct PullWorkspace {
-  int32_t *cnt_all, *nheavy, *cur_all, *baseU, *baseI, *offU, *offI, *heavyU, *heavyI, *occ1;
-  float* occ_g;
+  int32_t *cnt_all, *nheavy, *cur_all, *baseU, *baseI, *offU, *offI, *heavyU, *heavyI, *cnt_tile;
+  int2* occ1;
+  float *coeff, *g_item;
   int4 *rec1, *rec2;
   int2* occ2;
   int nbU, nbI;
@@ -495,9 +567,12 @@ inline PullWorkspace carve(void* base, int64_t B, int64_t nU, int64_t nI) {
   w.heavyI = (int32_t*)(p + o); o += align16((size_t)nI * 4);
   w.rec1 = (int4*)(p + o); o += align16((size_t)B * sizeof(int4));
   w.rec2 = (int4*)(p + o); o += align16((size_t)B * sizeof(int4));
-  w.occ1 = (int32_t*)(p + o); o += align16((size_t)B * 2 * 4);
+  w.occ1 = (int2*)(p + o); o += align16((size_t)B * 2 * sizeof(int2));
   w.occ2 = (int2*)(p + o); o += align16((size_t)B * 2 * sizeof(int2));
-  w.occ_g = (float*)(p + o); o += align16((size_t)B * 2 * 4);
+  w.coeff = (float*)(p + o); o += align16((size_t)B * 4);
+  w.g_item = (float*)(p + o); o += align16((size_t)B * 2 * 4);
+  const size_t ptiles = (size_t)((B + kPartTile - 1) / kPartTile);
+  w.cnt_tile = (int32_t*)(p + o); o += align16(ptiles * nb_all * 4);
   w.bytes = o;
   return w;
 }
@@ -524,22 +599,22 @@ static int pull_step_impl(const float* U_old, float* U_new, float* I, float* mU,
   const int ptiles = (int)((B + kPartTile - 1) / kPartTile);
   if (ptiles > 0)
     hipLaunchKernelGGL(part_count_kernel, dim3(ptiles), dim3(kPartThreads), (size_t)nb_all * 4, s, user, pos, neg, B,
-                       nU, nI, w.nbU, nb_all, w.cnt_all, err_flag);
+                       nU, nI, w.nbU, nb_all, w.cnt_all, w.cnt_tile, err_flag);
   hipLaunchKernelGGL(part_scan_kernel, dim3(2), dim3(kPartThreads), 0, s, w.cnt_all, w.nbU, w.nbI, w.baseU, w.baseI,
                      w.cur_all);
   if (ptiles > 0)
     hipLaunchKernelGGL(part_scatter_kernel, dim3(ptiles), dim3(kPartThreads), (size_t)nb_all * 8, s, user, pos, neg,
-                       B, nU, nI, w.nbU, nb_all, w.cur_all, w.rec1, w.occ1);
+                       B, nU, nI, w.nbU, nb_all, w.cur_all, w.cnt_tile, w.rec1, w.occ1);
   // 2. level-2 sort inside every bucket -> row offsets, records in row order, heavy lists
   SortSide su, si;
   su.base = w.baseU; su.off = w.offU; su.heavy = w.heavyU; su.nheavy = w.nheavy; su.buckets = w.nbU; su.rows = (int)nU;
   si.base = w.baseI; si.off = w.offI; si.heavy = w.heavyI; si.nheavy = w.nheavy + 1; si.buckets = w.nbI; si.rows = (int)nI;
   hipLaunchKernelGGL(bucket_sort_kernel, dim3(nb_all), dim3(kSortThreads), 0, s, su, si, w.rec1, w.occ1, w.rec2,
                      w.occ2, heavy_t);
-  // 3. user pass (reads U_old + I, writes U_new, occ_g, loss partials)
+  // 3. user pass (reads U_old + I, writes U_new, the coefficients in occ2, loss partials)
   RowPassArgs ua;
   ua.own_old = U_old; ua.own_new = U_new; ua.other = I; ua.m = mU; ua.v = vU; ua.grad_out = nullptr;
-  ua.off = w.offU; ua.rec = w.rec2; ua.occ = nullptr; ua.occ_g = w.occ_g;
+  ua.off = w.offU; ua.rec = w.rec2; ua.occ = nullptr; ua.coeff = w.coeff;
   ua.heavy = w.heavyU; ua.nheavy = w.nheavy; ua.loss_partials = loss_partials;
   ua.rows = (int)nU; ua.heavy_t = heavy_t; ua.inv_batch = inv_batch; ua.adam = adam;
   const int light_cap = YR_LOSS_PARTIALS - kHeavyBlocks;        // one loss-partial slot per workgroup
@@ -550,10 +625,14 @@ static int pull_step_impl(const float* U_old, float* U_new, float* I, float* mU,
   if (gu < YR_LOSS_PARTIALS)
     hipLaunchKernelGGL(pull_clear_partials_kernel, dim3((YR_LOSS_PARTIALS - gu + kBlock - 1) / kBlock), dim3(kBlock),
                        0, s, loss_partials, gu, YR_LOSS_PARTIALS);
-  // 4. item pass (reads U_old + occ_*, updates I in place or writes gradI_out)
+  // 4. coefficients into item order, then the item pass (reads U_old + occ2 + g_item, updates I in
+  //    place or writes gradI_out)
+  if (B > 0)
+    hipLaunchKernelGGL(pull_permute_coeff_kernel, dim3(grid_for(2 * B, kBlock)), dim3(kBlock), 0, s, w.occ2, w.coeff,
+                       w.baseI + w.nbI, w.g_item);
   RowPassArgs ia;
   ia.own_old = I; ia.own_new = I; ia.other = U_old; ia.m = mI; ia.v = vI; ia.grad_out = gradI_out;
-  ia.off = w.offI; ia.rec = nullptr; ia.occ = w.occ2; ia.occ_g = w.occ_g;
+  ia.off = w.offI; ia.rec = nullptr; ia.occ = w.occ2; ia.coeff = w.g_item;
   ia.heavy = w.heavyI; ia.nheavy = w.nheavy + 1; ia.loss_partials = nullptr;
   ia.rows = (int)nI; ia.heavy_t = heavy_t; ia.inv_batch = inv_batch; ia.adam = adam;
   int gi = (int)((nI + kWavesPerBlock - 1) / kWavesPerBlock);
