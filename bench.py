@@ -114,7 +114,9 @@ def main():
     def run(steps, timed):
         for k in range(steps):
             u, p, n = pool[k % n_pool]
-            step.step(u, p, n, record=timed)
+            # the following batch is known: at N > 1 its index is built under this step's all-reduce
+            nxt = pool[(k + 1) % n_pool] if (world > 1 and k + 1 < steps) else None
+            step.step(u, p, n, record=timed, next_batch=nxt)
 
     run(args.warmup, False)
     barrier()

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 7
+#define YR_ENGINE_VERSION 8
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -103,9 +103,9 @@ int yr_bpr_mf_fwd_bwd(const float *U, const float *I,
  * Sequence enqueued on `stream`: two-level counting sort of the batch by user and by item
  * (level 1: buckets of 64 rows, LDS histograms + one global integer atomic per workgroup and
  * bucket; level 2: LDS counting sort inside each bucket), a fused pass over the user rows
- * (scores, loss, user gradient in registers, Adam -> U_new; per-occurrence coefficients for
- * the item pass), a fused pass over the item rows (item gradient from the OLD user rows,
- * Adam in place).  See csrc/bpr_pull.hip.  Limits: num_users, num_items < 2^24.
+ * (scores, loss, user gradient in registers, Adam -> U_new; one coefficient per triplet for
+ * the item side), a gather of the coefficients into item order, a fused pass over the item
+ * rows (item gradient from the OLD user rows, Adam in place).  See csrc/bpr_pull.hip.  Limits: num_users, num_items < 2^24.
  *
  *   U_old  [num_users, D]  read;  U_new [num_users, D] written (must not alias U_old:
  *          the caller ping-pongs the two buffers between steps);
@@ -129,6 +129,24 @@ int yr_bpr_mf_pull_step(const float *U_old, float *U_new, float *I,
                         double beta1, double beta2, double eps, double weight_decay, int mode,
                         int heavy_threshold, void *workspace, int64_t workspace_bytes,
                         float *loss_partials, int32_t *err_flag, void *stream);
+
+/* The same step in two phases, for callers that overlap work:
+ *   yr_bpr_mf_pull_index  builds the batch index (the two-level counting sort) into `workspace`; it
+ *                         depends only on the triplets, so it may be enqueued for batch k+1 while
+ *                         the all-reduce of batch k is in flight (use a second workspace);
+ *   yr_bpr_mf_pull_apply  runs the fused user pass / item pass on an index built for the same
+ *                         B, num_users, num_items in the same workspace.
+ * yr_bpr_mf_pull_step == index followed by apply.                                           */
+int yr_bpr_mf_pull_index(const int64_t *user, const int64_t *pos, const int64_t *neg, int64_t B,
+                         int64_t num_users, int64_t num_items, int heavy_threshold,
+                         void *workspace, int64_t workspace_bytes, int32_t *err_flag, void *stream);
+int yr_bpr_mf_pull_apply(const float *U_old, float *U_new, float *I,
+                         float *mU, float *vU, float *mI, float *vI, float *gradI_out,
+                         int64_t B, int D, int64_t num_users, int64_t num_items, float inv_batch,
+                         double lr, double step_size, double bc2_sqrt,
+                         double beta1, double beta2, double eps, double weight_decay, int mode,
+                         int heavy_threshold, void *workspace, int64_t workspace_bytes,
+                         float *loss_partials, void *stream);
 
 /* ---------------------------------------------------------------------------
  * NGCF message passing            (reference models/ngcf.py:60-72, embedding_propagation:

@@ -49,9 +49,9 @@ class BPRMFStep:
         self.heavy_threshold = heavy_threshold
         self.U, self.I = U, I
         self._U_alt = torch.empty_like(U) if impl == "pull" else None
-        self._ws, self._ws_batch = None, 0
+        self._ws_slots, self._ws_batch, self._indexed = [None, None], [0, 0], None
         if impl == "pull" and max_batch:
-            self._workspace(max_batch)
+            self._workspace(max_batch, 0)
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.decoupled = optimizer.lower() == "adamw"
         self.world_size, self.pg = world_size, process_group
@@ -107,55 +107,83 @@ class BPRMFStep:
         return {k: (sum(a.elapsed_time(b) for a, b in v) * 1e3 / len(v), len(v), self._bytes[k])
                 for k, v in self._ev.items()}
 
-    def _workspace(self, batch):
-        if self._ws is None or batch > self._ws_batch:
-            self._ws = engine.bpr_mf_pull_workspace(batch, self.U.shape[0], self.I.shape[0], self.U.device)
-            self._ws_batch = batch
-        return self._ws
+    def _workspace(self, batch, slot=0):
+        """Scratch for the batch index; two slots so that the index of batch k+1 can be built while
+        batch k's all-reduce is in flight."""
+        ws = self._ws_slots[slot]
+        if ws is None or batch > self._ws_batch[slot]:
+            ws = engine.bpr_mf_pull_workspace(batch, self.U.shape[0], self.I.shape[0], self.U.device)
+            self._ws_slots[slot], self._ws_batch[slot] = ws, batch
+        return ws
 
     # -- the step -----------------------------------------------------------------------------
-    def step(self, u, p, n, record=False, global_batch=None):
+    def step(self, u, p, n, record=False, global_batch=None, next_batch=None):
         """One optimisation step on this rank's triplets.  ``global_batch``: size of the batch
         over ALL ranks (the mean of loss.py:27 is over it); default = local size x world_size,
-        i.e. equal slices."""
+        i.e. equal slices.  ``next_batch``: optional (u, p, n) of the following step — its index
+        (which does not depend on the tables) is then built while this step's all-reduce is in
+        flight, and the following ``step`` call finds it ready."""
         if global_batch is None:
             global_batch = u.numel() * self.world_size
         if self.impl_key == "pull":
-            return self._step_pull(u, p, n, record, global_batch)
+            return self._step_pull(u, p, n, record, global_batch, next_batch)
         return self._step_atomic(u, p, n, record, global_batch)
 
-    def _step_pull(self, u, p, n, record, global_batch):
+    def _check_triplets(self, u, p, n):
+        B = u.numel()
+        for name, t in (("user", u), ("pos", p), ("neg", n)):
+            if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.numel() == B):
+                raise engine.EngineError(f"{name}: need a contiguous int64 GPU tensor of length {B}")
+        return B
+
+    def _build_index(self, u, p, n, slot):
+        B = self._check_triplets(u, p, n)
+        ws = self._workspace(B, slot)
+        rc = self._lib.yr_bpr_mf_pull_index(u.data_ptr(), p.data_ptr(), n.data_ptr(), B, self.U.shape[0],
+                                            self.I.shape[0], self.heavy_threshold, ws.data_ptr(), ws.numel(),
+                                            self._pflag, torch.cuda.current_stream().cuda_stream)
+        if rc:
+            engine.check(rc, "yr_bpr_mf_pull_index")
+        # keep the tensors alive (and identify the batch) until the index is consumed
+        self._indexed = (slot, (u, p, n))
+
+    def _step_pull(self, u, p, n, record, global_batch, next_batch=None):
         B = u.numel()
         D = self.U.shape[1]
         inv = 1.0 / global_batch if global_batch else 0.0
         self.t += 1
-        ws = self._workspace(B)
         multi = self.world_size > 1 or self.split_item_update
         nU, nI = self.U.numel(), self.I.numel()
         # algorithmic bytes of the launch group: the per-triplet figure of SURVEY §8d plus the
         # dense Adam pass it absorbs (read p,m,v + write p,m,v on every row of both tables)
         alg = B * (24 + 24 * D) + 6 * 4 * (nU + (0 if multi else nI))
+        ready = self._indexed is not None and all(a is b for a, b in zip(self._indexed[1], (u, p, n)))
+        slot = self._indexed[0] if ready else 0
 
         def launch():
-            # lean host path (this call is the whole step): index tensors are checked here, the
+            # lean host path (these calls are the whole step): index tensors are checked here, the
             # long-lived buffers were checked when they were created
-            for name, t in (("user", u), ("pos", p), ("neg", n)):
-                if not (t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and t.numel() == B):
-                    raise engine.EngineError(f"{name}: need a contiguous int64 GPU tensor of length {B}")
+            if not ready:
+                self._build_index(u, p, n, slot)
+            ws = self._ws_slots[slot]
             step_size, bc2_sqrt = engine.adam_scalars(self.t, self.lr, self.betas[0], self.betas[1])
-            rc = self._lib.yr_bpr_mf_pull_step(
+            rc = self._lib.yr_bpr_mf_pull_apply(
                 self.U.data_ptr(), self._U_alt.data_ptr(), self._pI, self._pmU, self._pvU, self._pmI, self._pvI,
-                self.gI.data_ptr() if multi else None, u.data_ptr(), p.data_ptr(), n.data_ptr(),
-                B, D, self.U.shape[0], self.I.shape[0], inv, self.lr, step_size, bc2_sqrt,
-                self.betas[0], self.betas[1], self.eps, self.wd,
+                self.gI.data_ptr() if multi else None, B, D, self.U.shape[0], self.I.shape[0], inv, self.lr,
+                step_size, bc2_sqrt, self.betas[0], self.betas[1], self.eps, self.wd,
                 engine.OPT_ADAMW if self.decoupled else engine.OPT_ADAM, self.heavy_threshold,
-                ws.data_ptr(), ws.numel(), self._ppartials, self._pflag, torch.cuda.current_stream().cuda_stream)
+                ws.data_ptr(), ws.numel(), self._ppartials, torch.cuda.current_stream().cuda_stream)
             if rc:
-                engine.check(rc, "yr_bpr_mf_pull_step")
+                engine.check(rc, "yr_bpr_mf_pull_apply")
+            self._indexed = None
 
         def local_step():
             self._timed("bpr_pull_step", alg, record, launch)
             self.U, self._U_alt = self._U_alt, self.U
+
+        def overlap():
+            if next_batch is not None:
+                self._build_index(*next_batch, 1 - slot)
 
         def item_update():
             if multi:
@@ -163,7 +191,7 @@ class BPRMFStep:
                     self.I, self.gI, self.mI, self.vI, self.t, self.lr, self.betas[0], self.betas[1], self.eps,
                     self.wd, decoupled=self.decoupled, zero_grad=False))
 
-        sharded_item_exchange(local_step, item_update, self.gI, self.pg, self.world_size)
+        sharded_item_exchange(local_step, item_update, self.gI, self.pg, self.world_size, overlap)
         rc = self._lib.yr_loss_finalize(self._ppartials, inv, self.loss.data_ptr(), self.loss_accum.data_ptr(),
                                         torch.cuda.current_stream().cuda_stream)
         if rc:

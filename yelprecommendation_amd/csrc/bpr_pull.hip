@@ -586,14 +586,13 @@ extern "C" int64_t yr_bpr_mf_pull_workspace_bytes(int64_t max_batch, int64_t num
   return (int64_t)carve(nullptr, max_batch, num_users, num_items).bytes;
 }
 
-template <int D>
-static int pull_step_impl(const float* U_old, float* U_new, float* I, float* mU, float* vU, float* mI, float* vI,
-                          float* gradI_out, const int64_t* user, const int64_t* pos, const int64_t* neg, int64_t B,
-                          int64_t nU, int64_t nI, float inv_batch, const AdamC& adam, int heavy_t, void* workspace,
-                          float* loss_partials, int32_t* err_flag, hipStream_t s) {
+// phase 1: index build (independent of the tables: may run ahead, e.g. under the previous step's
+// all-reduce) -> workspace
+static int pull_index_impl(const int64_t* user, const int64_t* pos, const int64_t* neg, int64_t B, int64_t nU,
+                           int64_t nI, int heavy_t, void* workspace, int32_t* err_flag, hipStream_t s) {
   PullWorkspace w = carve(workspace, B, nU, nI);
   const int nb_all = w.nbU + w.nbI;
-  // 1. level-1 partition of the batch into user buckets and item buckets
+  // level-1 partition of the batch into user buckets and item buckets
   hipError_t e = hipMemsetAsync(w.cnt_all, 0, (size_t)((char*)w.nheavy - (char*)w.cnt_all) + 16, s);
   if (e != hipSuccess) return (int)e;
   const int ptiles = (int)((B + kPartTile - 1) / kPartTile);
@@ -605,13 +604,22 @@ static int pull_step_impl(const float* U_old, float* U_new, float* I, float* mU,
   if (ptiles > 0)
     hipLaunchKernelGGL(part_scatter_kernel, dim3(ptiles), dim3(kPartThreads), (size_t)nb_all * 8, s, user, pos, neg,
                        B, nU, nI, w.nbU, nb_all, w.cur_all, w.cnt_tile, w.rec1, w.occ1);
-  // 2. level-2 sort inside every bucket -> row offsets, records in row order, heavy lists
+  // level-2 sort inside every bucket -> row offsets, records in row order, heavy lists
   SortSide su, si;
   su.base = w.baseU; su.off = w.offU; su.heavy = w.heavyU; su.nheavy = w.nheavy; su.buckets = w.nbU; su.rows = (int)nU;
   si.base = w.baseI; si.off = w.offI; si.heavy = w.heavyI; si.nheavy = w.nheavy + 1; si.buckets = w.nbI; si.rows = (int)nI;
   hipLaunchKernelGGL(bucket_sort_kernel, dim3(nb_all), dim3(kSortThreads), 0, s, su, si, w.rec1, w.occ1, w.rec2,
                      w.occ2, heavy_t);
-  // 3. user pass (reads U_old + I, writes U_new, the coefficients in occ2, loss partials)
+  return launch_status();
+}
+
+// phase 2: the two fused row passes over an index built by phase 1 for the same batch
+template <int D>
+static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU, float* vU, float* mI, float* vI,
+                           float* gradI_out, int64_t B, int64_t nU, int64_t nI, float inv_batch, const AdamC& adam,
+                           int heavy_t, void* workspace, float* loss_partials, hipStream_t s) {
+  PullWorkspace w = carve(workspace, B, nU, nI);
+  // user pass (reads U_old + I, writes U_new, the per-triplet coefficients, loss partials)
   RowPassArgs ua;
   ua.own_old = U_old; ua.own_new = U_new; ua.other = I; ua.m = mU; ua.v = vU; ua.grad_out = nullptr;
   ua.off = w.offU; ua.rec = w.rec2; ua.occ = nullptr; ua.coeff = w.coeff;
@@ -625,8 +633,8 @@ static int pull_step_impl(const float* U_old, float* U_new, float* I, float* mU,
   if (gu < YR_LOSS_PARTIALS)
     hipLaunchKernelGGL(pull_clear_partials_kernel, dim3((YR_LOSS_PARTIALS - gu + kBlock - 1) / kBlock), dim3(kBlock),
                        0, s, loss_partials, gu, YR_LOSS_PARTIALS);
-  // 4. coefficients into item order, then the item pass (reads U_old + occ2 + g_item, updates I in
-  //    place or writes gradI_out)
+  // coefficients into item order, then the item pass (reads U_old + occ2 + g_item, updates I in
+  // place or writes gradI_out)
   if (B > 0)
     hipLaunchKernelGGL(pull_permute_coeff_kernel, dim3(grid_for(2 * B, kBlock)), dim3(kBlock), 0, s, w.occ2, w.coeff,
                        w.baseI + w.nbI, w.g_item);
@@ -645,24 +653,30 @@ static int pull_step_impl(const float* U_old, float* U_new, float* I, float* mU,
   return launch_status();
 }
 
-extern "C" int yr_bpr_mf_pull_step(const float* U_old, float* U_new, float* I, float* mU, float* vU, float* mI,
-                                   float* vI, float* gradI_out, const int64_t* user, const int64_t* pos,
-                                   const int64_t* neg, int64_t B, int D, int64_t num_users, int64_t num_items,
-                                   float inv_batch, double lr, double step_size, double bc2_sqrt, double beta1,
-                                   double beta2, double eps, double weight_decay, int mode, int heavy_threshold,
-                                   void* workspace, int64_t workspace_bytes, float* loss_partials,
-                                   int32_t* err_flag, void* stream) {
+static int pull_check_common(int64_t B, int64_t num_users, int64_t num_items, const void* workspace,
+                             int64_t workspace_bytes) {
   if (B < 0 || num_users <= 0 || num_items <= 0 || B > 0x3fffffff) return YR_ERR_BADARG;
   // ids share a 32-bit word with the 8-bit local row number inside a bucket
   if (num_users > kIdMask || num_items > kIdMask) return YR_ERR_UNSUPPORTED;
-  if (!U_old || !U_new || U_old == U_new || !I || !mU || !vU || !workspace || !loss_partials) return YR_ERR_BADARG;
-  if (!gradI_out && (!mI || !vI)) return YR_ERR_BADARG;
-  if (B > 0 && (!user || !pos || !neg)) return YR_ERR_BADARG;
-  if (mode != YR_OPT_ADAM && mode != YR_OPT_ADAMW) return YR_ERR_UNSUPPORTED;
-  if (heavy_threshold <= 0) heavy_threshold = 256;
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return YR_ERR_BADARG;
   if ((int64_t)carve(nullptr, B, num_users, num_items).bytes > workspace_bytes) return YR_ERR_BADARG;
-  if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return YR_ERR_BADARG;
-  AdamC c;
+  return 0;
+}
+
+extern "C" int yr_bpr_mf_pull_index(const int64_t* user, const int64_t* pos, const int64_t* neg, int64_t B,
+                                    int64_t num_users, int64_t num_items, int heavy_threshold, void* workspace,
+                                    int64_t workspace_bytes, int32_t* err_flag, void* stream) {
+  const int rc = pull_check_common(B, num_users, num_items, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (B > 0 && (!user || !pos || !neg)) return YR_ERR_BADARG;
+  if (heavy_threshold <= 0) heavy_threshold = 256;
+  return pull_index_impl(user, pos, neg, B, num_users, num_items, heavy_threshold, workspace, err_flag,
+                         (hipStream_t)stream);
+}
+
+static int make_adam(AdamC& c, double lr, double step_size, double bc2_sqrt, double beta1, double beta2, double eps,
+                     double weight_decay, int mode) {
+  if (mode != YR_OPT_ADAM && mode != YR_OPT_ADAMW) return YR_ERR_UNSUPPORTED;
   c.decay_mul = (float)(1.0 - lr * weight_decay);
   c.neg_step = (float)(-step_size);
   c.bc2_sqrt = (float)bc2_sqrt;
@@ -672,17 +686,53 @@ extern "C" int yr_bpr_mf_pull_step(const float* U_old, float* U_new, float* I, f
   c.eps = (float)eps;
   c.wd = (float)weight_decay;
   c.decoupled = mode == YR_OPT_ADAMW;
+  return 0;
+}
+
+extern "C" int yr_bpr_mf_pull_apply(const float* U_old, float* U_new, float* I, float* mU, float* vU, float* mI,
+                                    float* vI, float* gradI_out, int64_t B, int D, int64_t num_users,
+                                    int64_t num_items, float inv_batch, double lr, double step_size, double bc2_sqrt,
+                                    double beta1, double beta2, double eps, double weight_decay, int mode,
+                                    int heavy_threshold, void* workspace, int64_t workspace_bytes,
+                                    float* loss_partials, void* stream) {
+  int rc = pull_check_common(B, num_users, num_items, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!U_old || !U_new || U_old == U_new || !I || !mU || !vU || !loss_partials) return YR_ERR_BADARG;
+  if (!gradI_out && (!mI || !vI)) return YR_ERR_BADARG;
+  if (heavy_threshold <= 0) heavy_threshold = 256;
+  AdamC c;
+  rc = make_adam(c, lr, step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, mode);
+  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-#define YR_PULL_CASE(DD)                                                                                        \
+#define YR_APPLY_CASE(DD)                                                                                       \
   case DD:                                                                                                      \
-    return pull_step_impl<DD>(U_old, U_new, I, mU, vU, mI, vI, gradI_out, user, pos, neg, B, num_users,         \
-                              num_items, inv_batch, c, heavy_threshold, workspace, loss_partials, err_flag, s)
+    return pull_apply_impl<DD>(U_old, U_new, I, mU, vU, mI, vI, gradI_out, B, num_users, num_items, inv_batch,  \
+                               c, heavy_threshold, workspace, loss_partials, s)
   switch (D) {
-    YR_PULL_CASE(16);
-    YR_PULL_CASE(32);
-    YR_PULL_CASE(64);
-    YR_PULL_CASE(128);
+    YR_APPLY_CASE(16);
+    YR_APPLY_CASE(32);
+    YR_APPLY_CASE(64);
+    YR_APPLY_CASE(128);
     default: return YR_ERR_UNSUPPORTED;
   }
-#undef YR_PULL_CASE
+#undef YR_APPLY_CASE
+}
+
+extern "C" int yr_bpr_mf_pull_step(const float* U_old, float* U_new, float* I, float* mU, float* vU, float* mI,
+                                   float* vI, float* gradI_out, const int64_t* user, const int64_t* pos,
+                                   const int64_t* neg, int64_t B, int D, int64_t num_users, int64_t num_items,
+                                   float inv_batch, double lr, double step_size, double bc2_sqrt, double beta1,
+                                   double beta2, double eps, double weight_decay, int mode, int heavy_threshold,
+                                   void* workspace, int64_t workspace_bytes, float* loss_partials,
+                                   int32_t* err_flag, void* stream) {
+  if (D != 16 && D != 32 && D != 64 && D != 128) return YR_ERR_UNSUPPORTED;
+  if (mode != YR_OPT_ADAM && mode != YR_OPT_ADAMW) return YR_ERR_UNSUPPORTED;
+  if (!U_old || !U_new || U_old == U_new || !I || !mU || !vU || !loss_partials) return YR_ERR_BADARG;
+  if (!gradI_out && (!mI || !vI)) return YR_ERR_BADARG;
+  int rc = yr_bpr_mf_pull_index(user, pos, neg, B, num_users, num_items, heavy_threshold, workspace, workspace_bytes,
+                                err_flag, stream);
+  if (rc) return rc;
+  return yr_bpr_mf_pull_apply(U_old, U_new, I, mU, vU, mI, vI, gradI_out, B, D, num_users, num_items, inv_batch, lr,
+                              step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, mode, heavy_threshold, workspace,
+                              workspace_bytes, loss_partials, stream);
 }

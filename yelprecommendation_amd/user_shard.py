@@ -48,20 +48,28 @@ class UserShard:
         return (self.localize(user_id[m]),) + tuple(o[m] for o in others)
 
 
-def sharded_item_exchange(local_step, item_update, grad_item, group=None, world_size=1):
+def sharded_item_exchange(local_step, item_update, grad_item, group=None, world_size=1, overlap=None):
     """The one exchange step of the user-sharded BPR-MF step, backend-agnostic:
 
         local_step()            every rank: forward/backward on ITS triplets with
                                 inv_batch = 1 / B_global; user rows + their Adam state are updated
                                 locally; the dense local item gradient lands in ``grad_item``
-        all_reduce(grad_item)   SUM over ranks (RCCL over xGMI on MI355X; gloo in the CPU tests)
+        all_reduce(grad_item)   SUM over ranks (RCCL over xGMI on MI355X; gloo in the CPU tests),
+                                launched asynchronously
+        overlap()               optional: work that does not depend on the reduced gradient, enqueued
+                                while the collective is in flight (the next batch's index build)
         item_update()           identical dense Adam on the replicated item table on every rank
 
     ``bpr_step.BPRMFStep`` passes HIP-kernel closures; the CPU tests pass oracle closures to check
     that the sharded protocol reproduces the single-process step.
     """
     local_step()
+    work = None
     if world_size > 1:
         import torch.distributed as dist
-        dist.all_reduce(grad_item, op=dist.ReduceOp.SUM, group=group)
+        work = dist.all_reduce(grad_item, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    if overlap is not None:
+        overlap()
+    if work is not None:
+        work.wait()
     item_update()
