@@ -33,13 +33,16 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 8
+#define YR_ENGINE_VERSION 9
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
 
 #define YR_FLAG_BAD_USER 1
 #define YR_FLAG_BAD_ITEM 2
+
+#define YR_PULL_USER_PHASE 1 /* yr_bpr_mf_pull_apply: user pass + coefficient gather      */
+#define YR_PULL_ITEM_PHASE 2 /* yr_bpr_mf_pull_apply: item pass over [item_row_begin, end) */
 
 #define YR_OPT_ADAM  0 /* torch.optim.Adam  : grad += wd * p               */
 #define YR_OPT_ADAMW 1 /* torch.optim.AdamW : p *= 1 - lr * wd (decoupled) */
@@ -135,8 +138,12 @@ int yr_bpr_mf_pull_step(const float *U_old, float *U_new, float *I,
  *                         depends only on the triplets, so it may be enqueued for batch k+1 while
  *                         the all-reduce of batch k is in flight (use a second workspace);
  *   yr_bpr_mf_pull_apply  runs the fused user pass / item pass on an index built for the same
- *                         B, num_users, num_items in the same workspace.
- * yr_bpr_mf_pull_step == index followed by apply.                                           */
+ *                         B, num_users, num_items in the same workspace.  `phases` selects
+ *                         YR_PULL_USER_PHASE and/or YR_PULL_ITEM_PHASE; the item phase covers item
+ *                         rows [item_row_begin, item_row_end) only, so the item gradient can be
+ *                         produced (and all-reduced) in chunks.  The user phase must have run for
+ *                         the batch before any item phase.
+ * yr_bpr_mf_pull_step == index, then apply with both phases over all item rows.             */
 int yr_bpr_mf_pull_index(const int64_t *user, const int64_t *pos, const int64_t *neg, int64_t B,
                          int64_t num_users, int64_t num_items, int heavy_threshold,
                          void *workspace, int64_t workspace_bytes, int32_t *err_flag, void *stream);
@@ -146,7 +153,8 @@ int yr_bpr_mf_pull_apply(const float *U_old, float *U_new, float *I,
                          double lr, double step_size, double bc2_sqrt,
                          double beta1, double beta2, double eps, double weight_decay, int mode,
                          int heavy_threshold, void *workspace, int64_t workspace_bytes,
-                         float *loss_partials, void *stream);
+                         float *loss_partials, int phases, int64_t item_row_begin, int64_t item_row_end,
+                         void *stream);
 
 /* ---------------------------------------------------------------------------
  * NGCF message passing            (reference models/ngcf.py:60-72, embedding_propagation:

@@ -32,13 +32,16 @@ IMPL_NAMES = {
 class BPRMFStep:
     def __init__(self, U, I, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, optimizer="adam",
                  world_size=1, process_group=None, time_kernels=False, impl="pull", max_batch=0,
-                 heavy_threshold=0, state=None, split_item_update=False):
+                 heavy_threshold=0, state=None, split_item_update=False, item_chunks=2):
         """``state``: optional dict with pre-existing Adam tensors ``mU, vU, mI, vI`` (shared, updated
         in place) and the step count ``t`` — lets a trainer keep its torch-style optimizer state
         in sync with the fused step (see MFTrainer).
         ``split_item_update``: take the multi-GPU shape of the step (item pass emits the dense item
         gradient, then a separate dense Adam launch) even with one rank — used by tests."""
         self.split_item_update = split_item_update
+        # multi-GPU: the item pass / all-reduce / item Adam run in this many chunks of item rows so
+        # that chunk c is on the wire while chunk c+1 is computed
+        self.item_chunks = max(1, int(item_chunks))
         if optimizer.lower() not in ("adam", "adamw"):
             raise NotImplementedError(f"BPRMFStep: optimizer {optimizer}")
         if impl not in IMPL_NAMES:
@@ -160,38 +163,61 @@ class BPRMFStep:
         ready = self._indexed is not None and all(a is b for a, b in zip(self._indexed[1], (u, p, n)))
         slot = self._indexed[0] if ready else 0
 
-        def launch():
-            # lean host path (these calls are the whole step): index tensors are checked here, the
-            # long-lived buffers were checked when they were created
-            if not ready:
-                self._build_index(u, p, n, slot)
+        nchunks = self.item_chunks if multi else 1
+        rows = self.I.shape[0]
+        bounds = [rows * c // nchunks for c in range(nchunks + 1)]
+        both = engine.PULL_USER_PHASE | engine.PULL_ITEM_PHASE
+
+        def apply(phases, r0, r1):
             ws = self._ws_slots[slot]
             step_size, bc2_sqrt = engine.adam_scalars(self.t, self.lr, self.betas[0], self.betas[1])
             rc = self._lib.yr_bpr_mf_pull_apply(
                 self.U.data_ptr(), self._U_alt.data_ptr(), self._pI, self._pmU, self._pvU, self._pmI, self._pvI,
-                self.gI.data_ptr() if multi else None, B, D, self.U.shape[0], self.I.shape[0], inv, self.lr,
+                self.gI.data_ptr() if multi else None, B, D, self.U.shape[0], rows, inv, self.lr,
                 step_size, bc2_sqrt, self.betas[0], self.betas[1], self.eps, self.wd,
                 engine.OPT_ADAMW if self.decoupled else engine.OPT_ADAM, self.heavy_threshold,
-                ws.data_ptr(), ws.numel(), self._ppartials, torch.cuda.current_stream().cuda_stream)
+                ws.data_ptr(), ws.numel(), self._ppartials, phases, r0, r1,
+                torch.cuda.current_stream().cuda_stream)
             if rc:
                 engine.check(rc, "yr_bpr_mf_pull_apply")
-            self._indexed = None
 
-        def local_step():
-            self._timed("bpr_pull_step", alg, record, launch)
-            self.U, self._U_alt = self._U_alt, self.U
+        def first_chunk():
+            # lean host path (these calls are the whole step): index tensors are checked here, the
+            # long-lived buffers were checked when they were created
+            if not ready:
+                self._build_index(u, p, n, slot)
+            apply(both, bounds[0], bounds[1])
+            if nchunks == 1:
+                self._indexed = None
+
+        def local_first():
+            self._timed("bpr_pull_step", alg, record, first_chunk)
+
+        def make_chunk(c):
+            def run():
+                apply(engine.PULL_ITEM_PHASE, bounds[c], bounds[c + 1])
+                if c == nchunks - 1:
+                    self._indexed = None
+            return run
 
         def overlap():
             if next_batch is not None:
                 self._build_index(*next_batch, 1 - slot)
 
-        def item_update():
-            if multi:
-                self._timed("adam_dense_item", 7 * 4 * nI, record, lambda: engine.adam_dense(
-                    self.I, self.gI, self.mI, self.vI, self.t, self.lr, self.betas[0], self.betas[1], self.eps,
-                    self.wd, decoupled=self.decoupled, zero_grad=False))
+        def make_update(c):
+            def run():
+                if multi:
+                    r0, r1 = bounds[c], bounds[c + 1]
+                    self._timed("adam_dense_item", 7 * 4 * (r1 - r0) * D, record, lambda: engine.adam_dense(
+                        self.I[r0:r1], self.gI[r0:r1], self.mI[r0:r1], self.vI[r0:r1], self.t, self.lr,
+                        self.betas[0], self.betas[1], self.eps, self.wd, decoupled=self.decoupled, zero_grad=False))
+            return run
 
-        sharded_item_exchange(local_step, item_update, self.gI, self.pg, self.world_size, overlap)
+        steps = [local_first] + [make_chunk(c) for c in range(1, nchunks)]
+        grads = [self.gI[bounds[c]:bounds[c + 1]] for c in range(nchunks)] if multi else [None]
+        sharded_item_exchange(steps, [make_update(c) for c in range(nchunks)], grads, self.pg, self.world_size,
+                              overlap)
+        self.U, self._U_alt = self._U_alt, self.U
         rc = self._lib.yr_loss_finalize(self._ppartials, inv, self.loss.data_ptr(), self.loss_accum.data_ptr(),
                                         torch.cuda.current_stream().cuda_stream)
         if rc:

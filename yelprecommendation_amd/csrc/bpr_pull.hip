@@ -294,7 +294,8 @@ struct RowPassArgs {
   const int32_t* heavy;      // heavy-row list and its length
   const int32_t* nheavy;
   float* loss_partials;      // user pass
-  int rows;
+  int rows;                  // rows [row_begin, rows) ... the pass covers [row_begin, row_end)
+  int row_begin, row_end;
   int heavy_t;
   float inv_batch;
   AdamC adam;
@@ -476,6 +477,7 @@ __global__ __launch_bounds__(kBlock) void pull_rows_kernel(RowPassArgs a) {
     const int nh = a.nheavy[0];
     for (int h = blockIdx.x; h < nh; h += kHeavyBlocks) {
       const int row = a.heavy[h];
+      if (row < a.row_begin || row >= a.row_end) continue;      // workgroup-uniform
       const int lo = a.off[row], hi = a.off[row + 1];
       const float4 own = ld4(a.own_old + (int64_t)row * D + 4 * l);
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -496,7 +498,8 @@ __global__ __launch_bounds__(kBlock) void pull_rows_kernel(RowPassArgs a) {
     }
   } else {
     const int nwaves = (gridDim.x - kHeavyBlocks) * kWavesPerBlock;
-    for (int row = (blockIdx.x - kHeavyBlocks) * kWavesPerBlock + wave; row < a.rows; row += nwaves) {
+    for (int row = a.row_begin + (blockIdx.x - kHeavyBlocks) * kWavesPerBlock + wave; row < a.row_end;
+         row += nwaves) {
       const int lo = a.off[row], hi = a.off[row + 1];
       if (hi - lo > a.heavy_t) continue;
       const float4 own = ld4(a.own_old + (int64_t)row * D + 4 * l);
@@ -617,14 +620,17 @@ static int pull_index_impl(const int64_t* user, const int64_t* pos, const int64_
 template <int D>
 static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU, float* vU, float* mI, float* vI,
                            float* gradI_out, int64_t B, int64_t nU, int64_t nI, float inv_batch, const AdamC& adam,
-                           int heavy_t, void* workspace, float* loss_partials, hipStream_t s) {
+                           int heavy_t, void* workspace, float* loss_partials, int phases, int64_t item_begin,
+                           int64_t item_end, hipStream_t s) {
   PullWorkspace w = carve(workspace, B, nU, nI);
+  if (phases & YR_PULL_USER_PHASE) {
   // user pass (reads U_old + I, writes U_new, the per-triplet coefficients, loss partials)
   RowPassArgs ua;
   ua.own_old = U_old; ua.own_new = U_new; ua.other = I; ua.m = mU; ua.v = vU; ua.grad_out = nullptr;
   ua.off = w.offU; ua.rec = w.rec2; ua.occ = nullptr; ua.coeff = w.coeff;
   ua.heavy = w.heavyU; ua.nheavy = w.nheavy; ua.loss_partials = loss_partials;
-  ua.rows = (int)nU; ua.heavy_t = heavy_t; ua.inv_batch = inv_batch; ua.adam = adam;
+  ua.rows = (int)nU; ua.row_begin = 0; ua.row_end = (int)nU;
+  ua.heavy_t = heavy_t; ua.inv_batch = inv_batch; ua.adam = adam;
   const int light_cap = YR_LOSS_PARTIALS - kHeavyBlocks;        // one loss-partial slot per workgroup
   int gu = (int)((nU + kWavesPerBlock - 1) / kWavesPerBlock);
   if (gu > light_cap) gu = light_cap;
@@ -638,12 +644,15 @@ static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU
   if (B > 0)
     hipLaunchKernelGGL(pull_permute_coeff_kernel, dim3(grid_for(2 * B, kBlock)), dim3(kBlock), 0, s, w.occ2, w.coeff,
                        w.baseI + w.nbI, w.g_item);
+  }
+  if (!(phases & YR_PULL_ITEM_PHASE) || item_end <= item_begin) return launch_status();
   RowPassArgs ia;
   ia.own_old = I; ia.own_new = I; ia.other = U_old; ia.m = mI; ia.v = vI; ia.grad_out = gradI_out;
   ia.off = w.offI; ia.rec = nullptr; ia.occ = w.occ2; ia.coeff = w.g_item;
   ia.heavy = w.heavyI; ia.nheavy = w.nheavy + 1; ia.loss_partials = nullptr;
-  ia.rows = (int)nI; ia.heavy_t = heavy_t; ia.inv_batch = inv_batch; ia.adam = adam;
-  int gi = (int)((nI + kWavesPerBlock - 1) / kWavesPerBlock);
+  ia.rows = (int)nI; ia.row_begin = (int)item_begin; ia.row_end = (int)item_end;
+  ia.heavy_t = heavy_t; ia.inv_batch = inv_batch; ia.adam = adam;
+  int gi = (int)((item_end - item_begin + kWavesPerBlock - 1) / kWavesPerBlock);
   if (gi > kMaxGrid) gi = kMaxGrid;
   gi += kHeavyBlocks;
   if (gradI_out)
@@ -694,9 +703,12 @@ extern "C" int yr_bpr_mf_pull_apply(const float* U_old, float* U_new, float* I, 
                                     int64_t num_items, float inv_batch, double lr, double step_size, double bc2_sqrt,
                                     double beta1, double beta2, double eps, double weight_decay, int mode,
                                     int heavy_threshold, void* workspace, int64_t workspace_bytes,
-                                    float* loss_partials, void* stream) {
+                                    float* loss_partials, int phases, int64_t item_row_begin,
+                                    int64_t item_row_end, void* stream) {
   int rc = pull_check_common(B, num_users, num_items, workspace, workspace_bytes);
   if (rc) return rc;
+  if (!(phases & (YR_PULL_USER_PHASE | YR_PULL_ITEM_PHASE))) return YR_ERR_BADARG;
+  if (item_row_begin < 0 || item_row_end > num_items || item_row_begin > item_row_end) return YR_ERR_BADARG;
   if (!U_old || !U_new || U_old == U_new || !I || !mU || !vU || !loss_partials) return YR_ERR_BADARG;
   if (!gradI_out && (!mI || !vI)) return YR_ERR_BADARG;
   if (heavy_threshold <= 0) heavy_threshold = 256;
@@ -707,7 +719,8 @@ extern "C" int yr_bpr_mf_pull_apply(const float* U_old, float* U_new, float* I, 
 #define YR_APPLY_CASE(DD)                                                                                       \
   case DD:                                                                                                      \
     return pull_apply_impl<DD>(U_old, U_new, I, mU, vU, mI, vI, gradI_out, B, num_users, num_items, inv_batch,  \
-                               c, heavy_threshold, workspace, loss_partials, s)
+                               c, heavy_threshold, workspace, loss_partials, phases, item_row_begin,            \
+                               item_row_end, s)
   switch (D) {
     YR_APPLY_CASE(16);
     YR_APPLY_CASE(32);
@@ -734,5 +747,6 @@ extern "C" int yr_bpr_mf_pull_step(const float* U_old, float* U_new, float* I, f
   if (rc) return rc;
   return yr_bpr_mf_pull_apply(U_old, U_new, I, mU, vU, mI, vI, gradI_out, B, D, num_users, num_items, inv_batch, lr,
                               step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, mode, heavy_threshold, workspace,
-                              workspace_bytes, loss_partials, stream);
+                              workspace_bytes, loss_partials, YR_PULL_USER_PHASE | YR_PULL_ITEM_PHASE, 0, num_items,
+                              stream);
 }

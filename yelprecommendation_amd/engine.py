@@ -14,6 +14,7 @@ from ._lib import EngineError, check
 LOSS_PARTIALS = 2048        # YR_LOSS_PARTIALS
 FLAG_BAD_USER, FLAG_BAD_ITEM = 1, 2
 OPT_ADAM, OPT_ADAMW = 0, 1
+PULL_USER_PHASE, PULL_ITEM_PHASE = 1, 2
 SUPPORTED_WIDTHS = (16, 32, 64, 128)
 
 

@@ -48,28 +48,42 @@ class UserShard:
         return (self.localize(user_id[m]),) + tuple(o[m] for o in others)
 
 
-def sharded_item_exchange(local_step, item_update, grad_item, group=None, world_size=1, overlap=None):
-    """The one exchange step of the user-sharded BPR-MF step, backend-agnostic:
+def _as_list(x):
+    return list(x) if isinstance(x, (list, tuple)) else [x]
 
-        local_step()            every rank: forward/backward on ITS triplets with
-                                inv_batch = 1 / B_global; user rows + their Adam state are updated
-                                locally; the dense local item gradient lands in ``grad_item``
-        all_reduce(grad_item)   SUM over ranks (RCCL over xGMI on MI355X; gloo in the CPU tests),
-                                launched asynchronously
-        overlap()               optional: work that does not depend on the reduced gradient, enqueued
-                                while the collective is in flight (the next batch's index build)
-        item_update()           identical dense Adam on the replicated item table on every rank
+
+def sharded_item_exchange(local_step, item_update, grad_item, group=None, world_size=1, overlap=None):
+    """The exchange step of the user-sharded BPR-MF step, backend-agnostic.
+    Each of ``local_step``, ``item_update``, ``grad_item`` is one object or a list of C chunks
+    (chunk c covers a contiguous range of item rows):
+
+        local_step[c]()          every rank: work on ITS triplets with inv_batch = 1 / B_global; the
+                                 first chunk also updates the user rows and their Adam state
+                                 locally; chunk c leaves its rows of the dense local item gradient
+                                 in ``grad_item[c]``
+        all_reduce(grad_item[c]) SUM over ranks (RCCL over xGMI on MI355X; gloo in the CPU tests),
+                                 launched asynchronously right after local_step[c] — so chunk c is
+                                 on the wire while chunk c+1 is being computed
+        overlap()                optional: work that does not depend on the reduced gradient, enqueued
+                                 while the collectives are in flight (the next batch's index build)
+        item_update[c]()         identical dense Adam on the replicated item rows of chunk c, on
+                                 every rank, after chunk c's collective
 
     ``bpr_step.BPRMFStep`` passes HIP-kernel closures; the CPU tests pass oracle closures to check
     that the sharded protocol reproduces the single-process step.
     """
-    local_step()
-    work = None
-    if world_size > 1:
-        import torch.distributed as dist
-        work = dist.all_reduce(grad_item, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    steps, updates, grads = _as_list(local_step), _as_list(item_update), _as_list(grad_item)
+    if not (len(steps) == len(updates) == len(grads)):
+        raise ValueError("local_step / item_update / grad_item must have the same number of chunks")
+    works = []
+    for fn, g in zip(steps, grads):
+        fn()
+        if world_size > 1:
+            import torch.distributed as dist
+            works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True))
     if overlap is not None:
         overlap()
-    if work is not None:
-        work.wait()
-    item_update()
+    for k, upd in enumerate(updates):
+        if works:
+            works[k].wait()
+        upd()
