@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 9
+#define YR_ENGINE_VERSION 10
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -236,6 +236,20 @@ int yr_loss_finalize(const float *loss_partials, float scale,
 int yr_mf_scores_gemm(const float *U, const float *I, const int64_t *users, int64_t nrows, int D,
                       int64_t num_users, int64_t num_items, float *scores, int64_t row_stride,
                       int32_t *err_flag, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Fused evaluation: scores + mask + top-k without the score matrix
+ *   (reference trainers/mf_trainer.py:134-144 + :163-178 for all eval users at once)
+ *   out[r, 0..k) = the k best items of user users[r] by U[users[r]] . I[j], after forcing the
+ *   scores of the items in mask_idx[mask_ptr[r] .. mask_ptr[r+1]) to mask_value; score
+ *   descending, item id ascending among equal scores.  k <= 16.
+ * The mask lists must be sorted ASCENDING inside each row (the kernel walks them with a cursor as
+ * it sweeps the catalogue).  mask_ptr may be NULL.  f32 MFMA scores as yr_mf_scores_gemm.
+ * ------------------------------------------------------------------------- */
+int yr_mf_eval_topk(const float *U, const float *I, const int64_t *users, int64_t nrows, int D,
+                    int64_t num_users, int64_t num_items,
+                    const int64_t *mask_ptr, const int64_t *mask_idx, float mask_value,
+                    int k, int64_t *out, int32_t *err_flag, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Masked row-wise top-k      (reference trainers/mf_trainer.py:163-178,

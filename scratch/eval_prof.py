@@ -1,0 +1,14 @@
+import torch, sys
+sys.path.insert(0,'.')
+from yelprecommendation_amd import engine
+dev=torch.device('cuda:0')
+nu,ni,d=31668,38048,64
+g=torch.Generator(device=dev).manual_seed(0)
+U=torch.randn(nu,d,device=dev,generator=g)*0.1; I=torch.randn(ni,d,device=dev,generator=g)*0.1
+users=torch.arange(nu,device=dev)
+cnt=torch.randint(10,60,(nu,),device=dev,generator=g)
+ptr=torch.zeros(nu+1,dtype=torch.int64,device=dev); ptr[1:]=torch.cumsum(cnt,0)
+idx=torch.randint(0,ni,(int(ptr[-1]),),device=dev,generator=g)
+sidx=engine.sort_mask_rows(ptr,idx)
+for _ in range(3): engine.mf_eval_topk(U,I,users,ptr,sidx,10)
+torch.cuda.synchronize()

@@ -9,7 +9,13 @@ users=torch.arange(nu,device=dev)
 cnt=torch.randint(10,60,(nu,),device=dev,generator=g)
 ptr=torch.zeros(nu+1,dtype=torch.int64,device=dev); ptr[1:]=torch.cumsum(cnt,0)
 idx=torch.randint(0,ni,(int(ptr[-1]),),device=dev,generator=g)
-for _ in range(2):
-    torch.cuda.synchronize(); t=time.time()
-    out=engine.mf_recommend(U,I,users,ptr,idx,10)
-    torch.cuda.synchronize(); print('recommend all users', time.time()-t,'s')
+sidx=engine.sort_mask_rows(ptr,idx)
+for fused in (False, True):
+    for _ in range(2):
+        torch.cuda.synchronize(); t=time.time()
+        out=engine.mf_recommend(U,I,users,ptr,idx,10,fused=fused)
+        torch.cuda.synchronize(); print('fused' if fused else 'gemm+topk','recommend all users', round((time.time()-t)*1e3,2),'ms')
+torch.cuda.synchronize(); t=time.time()
+for _ in range(5): o2=engine.mf_eval_topk(U,I,users,ptr,sidx,10)
+torch.cuda.synchronize(); print('fused kernel only', round((time.time()-t)/5*1e3,2),'ms  -> ', round(2*nu*ni*d/((time.time()-t)/5)/1e12,1),'TFLOP/s f32')
+a=engine.mf_recommend(U,I,users,ptr,idx,10,fused=False); print('agree rows', (a==o2).all(1).float().mean().item())

@@ -144,7 +144,8 @@ def test_mf_scores_gemm_matches_oracle(device, d):
     np.testing.assert_allclose(S, ref, rtol=2e-5, atol=2e-6)
 
 
-def test_mf_recommend_matches_oracle(device):
+@pytest.mark.parametrize("fused", [True, False])
+def test_mf_recommend_matches_oracle(device, fused):
     from oracle import mf_eval
     from yelprecommendation_amd import engine
     rs = np.random.RandomState(77)
@@ -156,8 +157,31 @@ def test_mf_recommend_matches_oracle(device):
     idx = np.concatenate(lists).astype(np.int64)
     got = engine.mf_recommend(torch.from_numpy(U).to(device), torch.from_numpy(I).to(device),
                               torch.from_numpy(users).to(device), torch.from_numpy(ptr).to(device),
-                              torch.from_numpy(idx).to(device), k, chunk_users=64).cpu().numpy()
+                              torch.from_numpy(idx).to(device), k, chunk_users=64, fused=fused).cpu().numpy()
     want = mf_eval.recommend(U, I, users, ptr, idx, k)
     assert (got == want).all(axis=1).mean() >= 0.99
     for r in range(nu):
         assert not set(got[r].tolist()) & set(lists[r].tolist())
+
+
+@pytest.mark.parametrize("d", [16, 32, 64, 128])
+def test_fused_eval_topk_edge_cases(device, d):
+    """Fused kernel vs the unfused GEMM + top-k path: ragged user count (not a multiple of 64), item
+    count not a multiple of 128 or 32, empty mask rows, rows whose mask covers most of the catalogue
+    (masked items must then fill the tail with the mask value's order), k = 1 and k = 16."""
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(d)
+    nu, ni, n = 97, 333, 77
+    U, I = _tables(rs, nu, ni, d)
+    users = rs.randint(0, nu, size=n).astype(np.int64)
+    lists = []
+    for r in range(n):
+        m = 0 if r % 5 == 0 else (ni - 5 if r % 7 == 0 else rs.randint(1, 60))
+        lists.append(np.sort(rs.choice(ni, size=m, replace=False)))
+    ptr = np.zeros(n + 1, np.int64); ptr[1:] = np.cumsum([len(l) for l in lists])
+    idx = np.concatenate(lists).astype(np.int64)
+    t = lambda a: torch.from_numpy(a).to(device)
+    for k in (1, 10, 16):
+        a = engine.mf_recommend(t(U), t(I), t(users), t(ptr), t(idx), k, fused=True).cpu().numpy()
+        b = engine.mf_recommend(t(U), t(I), t(users), t(ptr), t(idx), k, fused=False).cpu().numpy()
+        assert (a == b).all(axis=1).mean() >= 0.98, (k, (a == b).all(axis=1).mean())

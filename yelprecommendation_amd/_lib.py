@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
-ENGINE_VERSION = 9
+ENGINE_VERSION = 10
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -49,6 +49,7 @@ SIGNATURES = {
                              _d, _d, _d, _d, _d, _d, _d, _int, _int, _p, _i64, _p, _int, _i64, _i64, _p],
     "yr_loss_finalize": [_p, _f, _p, _p, _p],
     "yr_mf_scores_gemm": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _p, _p],
+    "yr_mf_eval_topk": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _f, _int, _p, _p, _p],
     "yr_topk_masked": [_p, _i64, _i64, _i64, _p, _p, _f, _int, _p, _p],
     "yr_bpr_loss_fwd": [_p, _p, _i64, _p, _p],
     "yr_bpr_loss_bwd": [_p, _p, _p, _f, _i64, _p, _p, _p],

@@ -347,12 +347,47 @@ def mf_scores_gemm(U, I, users, out=None, err_flag=None):
     return out[:n]
 
 
-def mf_recommend(U, I, users, mask_ptr, mask_idx, k, chunk_users=4096):
+def sort_mask_rows(mask_ptr, mask_idx):
+    """Mask lists with the item ids ascending inside each row (index bookkeeping, done once per
+    eval set): what :func:`mf_eval_topk` requires."""
+    n = mask_ptr.numel() - 1
+    if mask_idx.numel() == 0:
+        return mask_idx
+    rows = torch.repeat_interleave(torch.arange(n, device=mask_idx.device), mask_ptr[1:] - mask_ptr[:-1])
+    span = int(mask_idx.max().item()) + 1
+    order = torch.argsort(rows * span + mask_idx)
+    return mask_idx[order].contiguous()
+
+
+def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALUE, out=None):
+    """Fused full-catalogue scoring + mask + top-k (no score matrix).  ``mask_idx_sorted``: CSR mask
+    lists with ascending ids inside each row (see :func:`sort_mask_rows`)."""
+    lib = _lib.load()
+    nu, ni, d = _table_dims(U, I)
+    n = users.numel()
+    if out is None:
+        out = torch.empty((n, k), dtype=torch.int64, device=U.device)
+    flag = new_error_flag(U.device)
+    check(lib.yr_mf_eval_topk(_dev(U, torch.float32, "U"), _dev(I, torch.float32, "I"),
+                              _dev(users, torch.int64, "users"), n, d, nu, ni,
+                              _opt(mask_ptr, torch.int64, "mask_ptr"), _opt(mask_idx_sorted, torch.int64, "mask_idx"),
+                              float(mask_value), int(k), _dev(out, torch.int64, "out"), flag.data_ptr(), _stream()),
+          "yr_mf_eval_topk")
+    raise_on_flag(flag, "mf_eval_topk")
+    return out
+
+
+def mf_recommend(U, I, users, mask_ptr, mask_idx, k, chunk_users=4096, fused=None):
     """Top-k unmasked items for each user id in ``users`` (reference
-    trainers/mf_trainer.py:134-144 + :163-178, batched): full-catalogue scores
-    ``U[users] @ I^T`` on the matrix cores, then per-user mask + top-k, all on the device."""
+    trainers/mf_trainer.py:134-144 + :163-178, batched), all on the device.
+    ``fused`` (default when k <= 16): one kernel, scores on the matrix cores with mask + top-k in the
+    epilogue.  Otherwise: score GEMM into a chunked buffer + the row-wise masked top-k kernel."""
     nu_tab, ni, d = _table_dims(U, I)
     n = users.numel()
+    if fused is None:
+        fused = k <= 16
+    if fused:
+        return mf_eval_topk(U, I, users.contiguous(), mask_ptr, sort_mask_rows(mask_ptr, mask_idx), k)
     out = torch.empty((n, k), dtype=torch.int64, device=U.device)
     flag = new_error_flag(U.device)
     chunk_users = max(1, min(chunk_users, n))
