@@ -111,3 +111,54 @@ def test_pull_equals_atomic_at_yelp_shape(device):
     assert abs(la - lb) <= 1e-5 * abs(lb)
     torch.testing.assert_close(a.U, b.U, rtol=1e-3, atol=1e-6)
     torch.testing.assert_close(a.I, b.I, rtol=1e-3, atol=1e-6)
+
+
+def test_auto_impl_switches_by_batch_and_stays_consistent(device):
+    """impl='auto': small batches take the atomic form, large ones the pull form, on the same state
+    (tables, Adam moments, step count); the mixed sequence must equal the all-pull sequence."""
+    from yelprecommendation_amd import bpr_step
+    from yelprecommendation_amd.bpr_step import BPRMFStep
+    rs = np.random.RandomState(123)
+    nu, ni, d = 500, 700, 64
+    U, I = _setup(rs, nu, ni, d)
+    old = bpr_step.AUTO_PULL_MIN_BATCH
+    bpr_step.AUTO_PULL_MIN_BATCH = 2000
+    try:
+        a = BPRMFStep(torch.from_numpy(U).to(device), torch.from_numpy(I).to(device), lr=5e-3, impl="auto")
+        b = BPRMFStep(torch.from_numpy(U).to(device), torch.from_numpy(I).to(device), lr=5e-3, impl="pull")
+        used = []
+        for B in (300, 5000, 1999, 2000, 64, 9000):
+            t = [torch.from_numpy(x).to(device) for x in _batch(rs, nu, ni, B, True)]
+            a.step(*t)
+            used.append(a.impl.split(":")[0])
+            b.step(*t)
+        assert used == ["atomic", "pull", "atomic", "pull", "atomic", "pull"]
+        assert abs(a.epoch_loss() - b.epoch_loss()) < 1e-5
+        torch.testing.assert_close(a.U, b.U, rtol=1e-3, atol=1e-5)
+        torch.testing.assert_close(a.I, b.I, rtol=1e-3, atol=1e-5)
+        a.check(); b.check()
+    finally:
+        bpr_step.AUTO_PULL_MIN_BATCH = old
+
+
+def test_item_gradient_columns_sum_to_zero_at_full_size(device):
+    """Size-independent property at BASELINE's full table size and batch: every triplet adds +g*u to
+    its positive item row and -g*u to its negative one, so the columns of the dense item gradient sum
+    to zero, and the user/item gradients are tied by  sum_rows(gradI[p]-side) = -sum_rows(...)."""
+    from yelprecommendation_amd.bpr_step import BPRMFStep
+    g = torch.Generator(device=device).manual_seed(5)
+    nu, ni, d, B = 31668, 38048, 64, 1 << 20
+    U = (torch.rand(nu, d, generator=g, device=device) - 0.5) * 0.1
+    I = (torch.rand(ni, d, generator=g, device=device) - 0.5) * 0.1
+    st = BPRMFStep(U, I, lr=1e-3, impl="pull", split_item_update=True, item_chunks=3)
+    u = torch.randint(0, nu, (B,), generator=g, device=device)
+    p = (torch.rand(B, generator=g, device=device).pow(3) * ni).long().clamp_(max=ni - 1)
+    n = torch.randint(0, ni, (B,), generator=g, device=device)
+    st.step(u, p, n)
+    st.check()
+    gI = st.gI.double()
+    col = gI.sum(0).abs().max().item()
+    scale = gI.abs().sum(0).max().item()
+    assert col <= 1e-5 * scale, (col, scale)
+    loss = st.epoch_loss()
+    assert 0.6 < loss < 0.75                       # near-zero scores => loss ~ ln 2

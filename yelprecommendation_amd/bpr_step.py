@@ -23,7 +23,12 @@ from . import engine
 from .user_shard import sharded_item_exchange
 
 
+# below this many triplets per step the float-atomic form wins (3 launches instead of 8; the
+# atomic ceiling only bites at large batches) — measured crossover ~100 k on MI355X
+AUTO_PULL_MIN_BATCH = 98304
+
 IMPL_NAMES = {
+    "auto": "auto: atomic scatter below %d triplets per step, pull above" % AUTO_PULL_MIN_BATCH,
     "pull": "pull: 2-level counting sort + fused per-row gather/score/loss/grad/Adam (no float atomics)",
     "atomic": "atomic: fused gather/score/loss + float-atomic scatter-add, dense Adam",
 }
@@ -31,7 +36,7 @@ IMPL_NAMES = {
 
 class BPRMFStep:
     def __init__(self, U, I, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, optimizer="adam",
-                 world_size=1, process_group=None, time_kernels=False, impl="pull", max_batch=0,
+                 world_size=1, process_group=None, time_kernels=False, impl="auto", max_batch=0,
                  heavy_threshold=0, state=None, split_item_update=False, item_chunks=2):
         """``state``: optional dict with pre-existing Adam tensors ``mU, vU, mI, vI`` (shared, updated
         in place) and the step count ``t`` — lets a trainer keep its torch-style optimizer state
@@ -51,18 +56,18 @@ class BPRMFStep:
                          if impl == "pull" else "bpr_fwd_bwd, adam_dense x2")
         self.heavy_threshold = heavy_threshold
         self.U, self.I = U, I
-        self._U_alt = torch.empty_like(U) if impl == "pull" else None
+        self._U_alt = None
         self._ws_slots, self._ws_batch, self._indexed = [None, None], [0, 0], None
         if impl == "pull" and max_batch:
             self._workspace(max_batch, 0)
+        self._gI_dirty = False
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.decoupled = optimizer.lower() == "adamw"
         self.world_size, self.pg = world_size, process_group
         dev = U.device
-        need_gU = impl == "atomic"
-        need_gI = impl == "atomic" or world_size > 1 or split_item_update
-        self.gU = torch.zeros_like(U) if need_gU else None
-        self.gI = torch.zeros_like(I) if need_gI else None
+        # buffers are created on first use by the implementation that needs them
+        self.gU = None
+        self.gI = torch.zeros_like(I) if (world_size > 1 or split_item_update) else None
         if state is not None:
             self.mU, self.vU, self.mI, self.vI = state["mU"], state["vU"], state["mI"], state["vI"]
             self.t = int(state.get("t", 0))
@@ -128,8 +133,19 @@ class BPRMFStep:
         flight, and the following ``step`` call finds it ready."""
         if global_batch is None:
             global_batch = u.numel() * self.world_size
-        if self.impl_key == "pull":
+        key = self.impl_key
+        if key == "auto":
+            key = "pull" if u.numel() >= AUTO_PULL_MIN_BATCH else "atomic"
+        if key == "pull":
+            if self._U_alt is None:
+                self._U_alt = torch.empty_like(self.U)
+            self.impl = IMPL_NAMES["pull"]
             return self._step_pull(u, p, n, record, global_batch, next_batch)
+        if self.gU is None:
+            self.gU = torch.zeros_like(self.U)
+        if self.gI is None:
+            self.gI = torch.zeros_like(self.I)
+        self.impl = IMPL_NAMES["atomic"]
         return self._step_atomic(u, p, n, record, global_batch)
 
     def _check_triplets(self, u, p, n):
@@ -217,6 +233,7 @@ class BPRMFStep:
         grads = [self.gI[bounds[c]:bounds[c + 1]] for c in range(nchunks)] if multi else [None]
         sharded_item_exchange(steps, [make_update(c) for c in range(nchunks)], grads, self.pg, self.world_size,
                               overlap)
+        self._gI_dirty = multi
         self.U, self._U_alt = self._U_alt, self.U
         rc = self._lib.yr_loss_finalize(self._ppartials, inv, self.loss.data_ptr(), self.loss_accum.data_ptr(),
                                         torch.cuda.current_stream().cuda_stream)
@@ -224,26 +241,44 @@ class BPRMFStep:
             engine.check(rc, "yr_loss_finalize")
 
     def _step_atomic(self, u, p, n, record, global_batch):
-        B = u.numel()
+        B = self._check_triplets(u, p, n)
         D = self.U.shape[1]
         inv = 1.0 / global_batch if global_batch else 0.0
-        self._timed("bpr_fwd_bwd", B * (24 + 24 * D), record, lambda: engine.bpr_mf_fwd_bwd(
-            self.U, self.I, u, p, n, self.gU, self.gI, self.partials, inv_batch=inv, err_flag=self.flag))
+        lib, stream = self._lib, torch.cuda.current_stream().cuda_stream
+        if self._gI_dirty:                      # a pull-form multi-GPU step left the reduced gradient there
+            self.gI.zero_()
+            self._gI_dirty = False
+        nU, nI = self.U.shape[0], self.I.shape[0]
+        pU, pgU, pgI = self.U.data_ptr(), self.gU.data_ptr(), self.gI.data_ptr()
+
+        def fwd_bwd():
+            rc = lib.yr_bpr_mf_fwd_bwd(pU, self._pI, u.data_ptr(), p.data_ptr(), n.data_ptr(), B, D, nU, nI, inv,
+                                       pgU, pgI, self._ppartials, self._pflag, stream)
+            if rc:
+                engine.check(rc, "yr_bpr_mf_fwd_bwd")
+
+        self._timed("bpr_fwd_bwd", B * (24 + 24 * D), record, fwd_bwd)
         work = None
         if self.world_size > 1:
             import torch.distributed as dist
             work = dist.all_reduce(self.gI, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        engine.loss_finalize(self.partials, inv, self.loss, self.loss_accum)
+        rc = lib.yr_loss_finalize(self._ppartials, inv, self.loss.data_ptr(), self.loss_accum.data_ptr(), stream)
+        if rc:
+            engine.check(rc, "yr_loss_finalize")
         self.t += 1
-        nU, nI = self.U.numel(), self.I.numel()
-        self._timed("adam_dense_user", 8 * 4 * nU, record, lambda: engine.adam_dense(
-            self.U, self.gU, self.mU, self.vU, self.t, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-            decoupled=self.decoupled, zero_grad=True))
+        step_size, bc2_sqrt = engine.adam_scalars(self.t, self.lr, self.betas[0], self.betas[1])
+        mode = engine.OPT_ADAMW if self.decoupled else engine.OPT_ADAM
+
+        def adam(ptr, g, m, v, count):
+            rc = lib.yr_adam_dense(ptr, g, m, v, count, self.lr, step_size, bc2_sqrt, self.betas[0], self.betas[1],
+                                   self.eps, self.wd, mode, 1, stream)
+            if rc:
+                engine.check(rc, "yr_adam_dense")
+
+        self._timed("adam_dense_user", 8 * 4 * nU * D, record, lambda: adam(pU, pgU, self._pmU, self._pvU, nU * D))
         if work is not None:
             work.wait()
-        self._timed("adam_dense_item", 8 * 4 * nI, record, lambda: engine.adam_dense(
-            self.I, self.gI, self.mI, self.vI, self.t, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-            decoupled=self.decoupled, zero_grad=True))
+        self._timed("adam_dense_item", 8 * 4 * nI * D, record, lambda: adam(self._pI, pgI, self._pmI, self._pvI, nI * D))
 
     def epoch_loss(self, reset=True):
         """Sum of per-batch mean losses since the last reset (one host sync).  At N > 1 the

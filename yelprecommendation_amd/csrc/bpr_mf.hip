@@ -33,11 +33,12 @@ __device__ __forceinline__ Row<D> load_row(const float* __restrict__ T, int32_t 
 }
 
 // Stage one tile of triplets into LDS as int32, -1 for tail / out-of-range entries.
-template <int NIDX>
-__device__ __forceinline__ int stage_indices(int32_t (*s_idx)[kTile], const int64_t* const* idx,
+template <int NIDX, int TILE = kTile>
+__device__ __forceinline__ int stage_indices(int32_t (*s_idx)[TILE], const int64_t* const* idx,
                                              const int64_t* limit, const int* flag_bit,
                                              int64_t tile, int64_t B) {
-  const int64_t b = tile * kTile + threadIdx.x;
+  if (TILE < kBlock && (int)threadIdx.x >= TILE) return 0;
+  const int64_t b = tile * TILE + threadIdx.x;
   int32_t v[NIDX];
   int bad = 0;
 #pragma unroll
@@ -62,7 +63,10 @@ __device__ __forceinline__ int stage_indices(int32_t (*s_idx)[kTile], const int6
 // ---------------------------------------------------------------------------
 // fused forward + loss (+ backward scatter-add when BWD)
 // ---------------------------------------------------------------------------
-template <int D, bool BWD>
+// TILE triplets are staged per workgroup iteration, TILE/4 per wave: 256 for throughput, 64 for
+// small batches (4x the workgroups, a quarter of the serial passes per wave: latency, not bandwidth,
+// is what a 32..16k-triplet step waits for).
+template <int D, bool BWD, int TILE>
 __global__ __launch_bounds__(kBlock) void bpr_fwd_bwd_kernel(
     const float* __restrict__ U, const float* __restrict__ I,
     const int64_t* __restrict__ user, const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
@@ -70,32 +74,37 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_bwd_kernel(
     float* __restrict__ gradU, float* __restrict__ gradI,
     float* __restrict__ loss_partials, int32_t* __restrict__ err_flag) {
   using G = RowGeom<D>;
-  __shared__ int32_t s_idx[3][kTile];
+  constexpr int PER_WAVE = TILE / kWavesPerBlock;
+  __shared__ int32_t s_idx[3][TILE];
   __shared__ float s_red[kWavesPerBlock];
 
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int sub = lane / G::LPR, l = lane % G::LPR;
+  // slots of the partial-sum array no workgroup owns
+  if (blockIdx.x == 0)
+    for (int i = gridDim.x + threadIdx.x; i < YR_LOSS_PARTIALS; i += kBlock) loss_partials[i] = 0.0f;
   const int64_t* idx[3] = {user, pos, neg};
   const int64_t limit[3] = {num_users, num_items, num_items};
   const int flag_bit[3] = {YR_FLAG_BAD_USER, YR_FLAG_BAD_ITEM, YR_FLAG_BAD_ITEM};
 
   float loss_acc = 0.0f;
   int bad = 0;
-  const int64_t ntiles = (B + kTile - 1) / kTile;
+  const int64_t ntiles = (B + TILE - 1) / TILE;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    bad |= stage_indices<3>(s_idx, idx, limit, flag_bit, tile, B);
+    bad |= stage_indices<3, TILE>(s_idx, idx, limit, flag_bit, tile, B);
     __syncthreads();
 
-    // this wave owns triplets [wave*64, wave*64+64) of the tile
-    for (int k = 0; k < kWave; k += G::RPW * kUnroll) {
+    // this wave owns triplets [wave*PER_WAVE, (wave+1)*PER_WAVE) of the tile
+    for (int k = 0; k < PER_WAVE; k += G::RPW * kUnroll) {
       int32_t uu[kUnroll], pp[kUnroll], nn[kUnroll];
       Row<D> ru[kUnroll], rp[kUnroll], rn[kUnroll];
 #pragma unroll
       for (int q = 0; q < kUnroll; ++q) {
-        const int t = wave * kWave + k + q * G::RPW + sub;
-        uu[q] = s_idx[0][t];
-        pp[q] = s_idx[1][t];
-        nn[q] = s_idx[2][t];
+        const int t = wave * PER_WAVE + k + q * G::RPW + sub;
+        const bool in = k + q * G::RPW + sub < PER_WAVE;      // D = 16 with the small tile: 16 slots, 16 triplets
+        uu[q] = in ? s_idx[0][t] : -1;
+        pp[q] = in ? s_idx[1][t] : -1;
+        nn[q] = in ? s_idx[2][t] : -1;
       }
 #pragma unroll
       for (int q = 0; q < kUnroll; ++q) {
@@ -303,25 +312,24 @@ extern "C" int yr_bpr_mf_fwd_bwd(const float* U, const float* I, const int64_t* 
   if (B < 0 || num_users <= 0 || num_items <= 0 || !loss_partials) return YR_ERR_BADARG;
   if ((gradU == nullptr) != (gradI == nullptr)) return YR_ERR_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  int grid = 0;
-  if (B > 0) {
-    if (!U || !I || !user || !pos || !neg) return YR_ERR_BADARG;
-    grid = grid_for(B, kTile);
-    if (gradU) {
-      YR_DISPATCH_D(D, hipLaunchKernelGGL((bpr_fwd_bwd_kernel<kD, true>), dim3(grid), dim3(kBlock), 0, s, U, I,
-                                           user, pos, neg, B, num_users, num_items, inv_batch, gradU, gradI,
-                                           loss_partials, err_flag));
-    } else {
-      YR_DISPATCH_D(D, hipLaunchKernelGGL((bpr_fwd_bwd_kernel<kD, false>), dim3(grid), dim3(kBlock), 0, s, U, I,
-                                           user, pos, neg, B, num_users, num_items, inv_batch, gradU, gradI,
-                                           loss_partials, err_flag));
-    }
+  if (B == 0) {
+    hipLaunchKernelGGL(clear_tail_kernel, dim3(YR_LOSS_PARTIALS / kBlock), dim3(kBlock), 0, s, loss_partials, 0,
+                       YR_LOSS_PARTIALS);
+    return launch_status();
   }
-  if (grid < YR_LOSS_PARTIALS) {
-    const int rest = YR_LOSS_PARTIALS - grid;
-    hipLaunchKernelGGL(clear_tail_kernel, dim3((rest + kBlock - 1) / kBlock), dim3(kBlock), 0, s, loss_partials,
-                       grid, YR_LOSS_PARTIALS);
+  if (!U || !I || !user || !pos || !neg) return YR_ERR_BADARG;
+  const bool small = B <= 16384;                       // latency regime: 64-triplet tiles
+  const int grid = grid_for(B, small ? 64 : kTile);
+#define YR_LAUNCH_FB(BWD, TILE)                                                                                \
+  YR_DISPATCH_D(D, hipLaunchKernelGGL((bpr_fwd_bwd_kernel<kD, BWD, TILE>), dim3(grid), dim3(kBlock), 0, s, U, I, \
+                                      user, pos, neg, B, num_users, num_items, inv_batch, gradU, gradI,          \
+                                      loss_partials, err_flag))
+  if (gradU) {
+    if (small) { YR_LAUNCH_FB(true, 64); } else { YR_LAUNCH_FB(true, kTile); }
+  } else {
+    if (small) { YR_LAUNCH_FB(false, 64); } else { YR_LAUNCH_FB(false, kTile); }
   }
+#undef YR_LAUNCH_FB
   return launch_status();
 }
 
