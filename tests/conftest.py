@@ -11,6 +11,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by `pytest -m gpu` on the GPU box)")
+    # the C-ABI library is a build artefact (git-ignored): build it if this tree has none yet
+    lib = os.path.join(ROOT, "yelprecommendation_amd", "libyelprec_engine.so")
+    if not os.path.exists(lib):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
