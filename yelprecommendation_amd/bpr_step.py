@@ -52,8 +52,7 @@ class BPRMFStep:
         if impl not in IMPL_NAMES:
             raise ValueError(f"impl must be one of {list(IMPL_NAMES)}")
         self.impl_key, self.impl = impl, IMPL_NAMES[impl]
-        self.launches = ("part_count, part_scan, part_scatter, bucket_sort, pull_rows<user>, pull_rows<item>"
-                         if impl == "pull" else "bpr_fwd_bwd, adam_dense x2")
+        self.launches = ""
         self.heavy_threshold = heavy_threshold
         self.U, self.I = U, I
         self._U_alt = None
@@ -140,12 +139,15 @@ class BPRMFStep:
             if self._U_alt is None:
                 self._U_alt = torch.empty_like(self.U)
             self.impl = IMPL_NAMES["pull"]
+            self.launches = ("part_count, part_scan, part_scatter, bucket_sort, pull_rows<user>, permute_coeff, "
+                             "pull_rows<item>")
             return self._step_pull(u, p, n, record, global_batch, next_batch)
         if self.gU is None:
             self.gU = torch.zeros_like(self.U)
         if self.gI is None:
             self.gI = torch.zeros_like(self.I)
         self.impl = IMPL_NAMES["atomic"]
+        self.launches = "bpr_fwd_bwd, adam_dense x2"
         return self._step_atomic(u, p, n, record, global_batch)
 
     def _check_triplets(self, u, p, n):
