@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 10
+#define YR_ENGINE_VERSION 11
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -265,6 +265,19 @@ int yr_mf_eval_topk(const float *U, const float *I, const int64_t *users, int64_
 int yr_topk_masked(const float *scores, int64_t nrows, int64_t ncols, int64_t row_stride,
                    const int64_t *mask_ptr, const int64_t *mask_idx, float mask_value,
                    int k, int64_t *out, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Ranking metrics on the device      (reference metric.py:7-109, with its quirks: recall / MAP /
+ *   NDCG skip users with an empty `actual` and shrink the denominator; AP truncates `actual` too
+ *   and divides by len(actual); DCG scans positions 1..min(len(actual), k) only)
+ *   topk [n, k] int64 (e.g. from yr_mf_eval_topk), pos_ptr [n+1] / pos_idx: the held-out items of
+ *   each row in their ORIGINAL order (AP depends on it).
+ *   out[0..3] = precision@k, recall@k, MAP@k, NDCG@k (float64), out[4] = users with non-empty
+ *   `actual`.  workspace: yr_rank_metrics_workspace_bytes(n) bytes.
+ * ------------------------------------------------------------------------- */
+int64_t yr_rank_metrics_workspace_bytes(int64_t n);
+int yr_rank_metrics(const int64_t *topk, int64_t n, int k, const int64_t *pos_ptr, const int64_t *pos_idx,
+                    double *workspace, double *out, void *stream);
 
 /* ---------------------------------------------------------------------------
  * BPRLoss.forward / backward on score vectors        (reference loss.py:25-27)

@@ -131,3 +131,31 @@ def test_reference_style_loop_matches_fused(g, tmp_path, device):
     np.testing.assert_allclose(losses, g["train_step_loss"][:20], rtol=1e-4)
     np.testing.assert_allclose(a.model.item_embedding.weight.detach().cpu().numpy(),
                                b.model.item_embedding.weight.detach().cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_device_metrics_match_reference_definition(device, golden_dir):
+    """yr_rank_metrics vs the host functions (the reference's definitions, pinned by its KATs and by
+    metric_cases.npz): ragged lists, empty `actual` rows, duplicates inside `actual`, all k."""
+    from yelprecommendation_amd import engine, metric
+    c = np.load(os.path.join(golden_dir, "metric_cases.npz"))
+    u0 = 0
+    for case, (nu, k) in enumerate(zip(c["case_users"], c["k"])):
+        actual = [c["actual_idx"][c["actual_ptr"][u]:c["actual_ptr"][u + 1]].tolist() for u in range(u0, u0 + nu)]
+        predicted = c["predicted"][u0:u0 + nu]
+        u0 += nu
+        ptr = np.zeros(nu + 1, np.int64); ptr[1:] = np.cumsum([len(a) for a in actual])
+        idx = np.asarray([x for a in actual for x in a], dtype=np.int64)
+        out = engine.rank_metrics(torch.from_numpy(np.ascontiguousarray(predicted[:, :int(k)])).to(device),
+                                  torch.from_numpy(ptr).to(device), torch.from_numpy(idx).to(device)).cpu().numpy()
+        np.testing.assert_allclose(out[:4], c["values"][case], rtol=1e-12, atol=1e-15)
+    # the reference's own known-answer test (test/test_metric.py:9-47) and a case with duplicates
+    actual = [[1, 2, 3, 4, 5], [6, 7, 8, 9, 10], [], [3, 3, 9, 3]]
+    predicted = np.array([[1, 6, 7, 11, 12], [6, 7, 14, 16, 20], [1, 2, 3, 4, 5], [9, 3, 1, 2, 4]], dtype=np.int64)
+    ptr = np.zeros(5, np.int64); ptr[1:] = np.cumsum([len(a) for a in actual])
+    idx = np.asarray([x for a in actual for x in a], dtype=np.int64)
+    for k in (1, 2, 3, 5):
+        out = engine.rank_metrics(torch.from_numpy(np.ascontiguousarray(predicted[:, :k])).to(device),
+                                  torch.from_numpy(ptr).to(device), torch.from_numpy(idx).to(device)).cpu().numpy()
+        want = metric.ranking_metrics(actual, predicted.tolist(), k)
+        np.testing.assert_allclose(out[:4], want, rtol=1e-12)
+        assert out[4] == 3
