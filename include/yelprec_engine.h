@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 11
+#define YR_ENGINE_VERSION 12
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -172,7 +172,22 @@ int yr_bpr_mf_pull_apply(const float *U_old, float *U_new, float *I,
  * yr_ngcf_dense_bwd_weight: dW1 += dP^T (Z + E); dW2 += dP^T (E * Z)   (float atomics on the
  *   2 D^2 outputs; caller zero-fills).
  * The backward SpMM (dE += L^T dZ) is yr_spmm_csr with accumulate = 1: L is symmetric.
+ * yr_ngcf_score_fwd: the tail of NGCF.bpr_forward / forward (models/ngcf.py:44-58, :26-41): the
+ *   layer outputs E_0..E_K ([num_users + num_items, D] each; users first) are concatenated along
+ *   the feature axis and scored by a dot product = the sum over layers of per-layer dot products:
+ *   out_pos[b] = sum_k <E_k[user[b]], E_k[num_users + pos[b]]>, out_neg likewise with neg.
+ *   `layers` is a HOST array of n_layers (<= YR_NGCF_MAX_LAYERS) device pointers.  neg / out_neg
+ *   may both be NULL (forward(user, item)).  Out-of-range ids: flag raised, score 0.
+ * yr_ngcf_score_bwd: its autograd — dlayers[k] (host array of device pointers, caller zero-fills
+ *   or accumulates) += gradient of every layer buffer, float atomics (like index_add_).
  * ------------------------------------------------------------------------- */
+#define YR_NGCF_MAX_LAYERS 8
+int yr_ngcf_score_fwd(const float *const *layers, int n_layers, const int64_t *user, const int64_t *pos,
+                      const int64_t *neg, int64_t B, int D, int64_t num_users, int64_t num_items,
+                      float *out_pos, float *out_neg, int32_t *err_flag, void *stream);
+int yr_ngcf_score_bwd(const float *const *layers, float *const *dlayers, int n_layers, const int64_t *user,
+                      const int64_t *pos, const int64_t *neg, const float *gpos, const float *gneg,
+                      int64_t B, int D, int64_t num_users, int64_t num_items, int32_t *err_flag, void *stream);
 int yr_spmm_csr(const int32_t *rowptr, const int32_t *col, const float *val,
                 const float *X, float *Y, int64_t n, int D, int accumulate,
                 const int32_t *heavy_rows, int64_t n_heavy, int heavy_threshold, void *stream);

@@ -220,3 +220,59 @@ def test_training_steps_match_oracle_on_skewed_graph(device, tmp_path):
     np.testing.assert_allclose(model.embedding.weight.detach().cpu().numpy(), ref.E, rtol=2e-3, atol=2e-4)
     np.testing.assert_allclose(model.W1[K - 1].weight.detach().cpu().numpy(), ref.W1[K - 1], rtol=2e-3, atol=2e-4)
     np.testing.assert_allclose(model.W2[0].weight.detach().cpu().numpy(), ref.W2[0], rtol=2e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("d,layers,with_neg", [(16, 1, True), (32, 3, True), (64, 4, True), (64, 4, False),
+                                               (128, 8, True)])
+def test_layer_sum_scores_match_concat_definition(device, d, layers, with_neg):
+    """yr_ngcf_score_fwd/_bwd vs the reference's definition (models/ngcf.py:44-58): concatenate the
+    layer outputs, index users and items, multiply, sum — and its autograd; ragged batch sizes
+    (not a multiple of the lane-group count) and repeated ids (atomics)."""
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(layers * 1000 + d)
+    nu, ni = 37, 53
+    for B in (1, 7, 64, 1001):
+        Es = [rs.standard_normal((nu + ni, d)).astype(np.float32) for _ in range(layers)]
+        u = rs.randint(0, nu, B); p = rs.randint(0, ni, B); n = rs.randint(0, ni, B)
+        gp = rs.standard_normal(B).astype(np.float32); gn = rs.standard_normal(B).astype(np.float32)
+        # float64 statement of the definition
+        cat = np.concatenate(Es, axis=1).astype(np.float64)
+        want_pos = (cat[u] * cat[nu + p]).sum(1)
+        want_neg = (cat[u] * cat[nu + n]).sum(1)
+        dcat = np.zeros_like(cat)
+        np.add.at(dcat, u, gp[:, None] * cat[nu + p]); np.add.at(dcat, nu + p, gp[:, None] * cat[u])
+        if with_neg:
+            np.add.at(dcat, u, gn[:, None] * cat[nu + n]); np.add.at(dcat, nu + n, gn[:, None] * cat[u])
+        T = [torch.from_numpy(E).to(device) for E in Es]
+        tu, tp, tn = (torch.from_numpy(x).to(device) for x in (u, p, n))
+        flag = torch.zeros(1, dtype=torch.int32, device=device)
+        res = engine.ngcf_score(T, nu, tu, tp, tn if with_neg else None, err_flag=flag)
+        pos, neg = res if with_neg else (res, None)
+        scale = np.abs(cat).max() ** 2 * cat.shape[1]
+        np.testing.assert_allclose(pos.cpu().numpy(), want_pos, atol=2e-6 * scale)
+        if with_neg:
+            np.testing.assert_allclose(neg.cpu().numpy(), want_neg, atol=2e-6 * scale)
+        dT = [torch.zeros_like(t) for t in T]
+        engine.ngcf_score_backward(T, dT, nu, tu, tp, tn if with_neg else None, torch.from_numpy(gp).to(device),
+                                   torch.from_numpy(gn).to(device) if with_neg else None, err_flag=flag)
+        got = np.concatenate([t.cpu().numpy() for t in dT], axis=1)
+        np.testing.assert_allclose(got, dcat, atol=1e-5 * max(1.0, np.abs(dcat).max()))
+        assert int(flag.item()) == 0
+
+
+def test_layer_sum_scores_flag_bad_ids(device):
+    from yelprecommendation_amd import engine
+    nu, ni, d = 10, 12, 64
+    T = [torch.randn(nu + ni, d, device=device) for _ in range(2)]
+    u = torch.tensor([0, 10, 3, -1], device=device); p = torch.tensor([1, 2, 12, 4], device=device)
+    n = torch.tensor([0, 1, 2, 3], device=device)
+    flag = torch.zeros(1, dtype=torch.int32, device=device)
+    pos, neg = engine.ngcf_score(T, nu, u, p, n, err_flag=flag)
+    assert int(flag.item()) == engine.FLAG_BAD_USER | engine.FLAG_BAD_ITEM
+    assert pos[1:].abs().max().item() == 0.0 and neg[1:].abs().max().item() == 0.0 and pos[0].item() != 0.0
+    dT = [torch.zeros_like(t) for t in T]
+    engine.ngcf_score_backward(T, dT, nu, u, p, n, torch.ones(4, device=device), torch.ones(4, device=device))
+    touched = (dT[0].abs().sum(1) > 0).nonzero().flatten().tolist()
+    assert touched == [0, nu + 0, nu + 1]                    # only the valid triplet (0, 1, 0) scatters
+    with pytest.raises(engine.EngineError):
+        engine.ngcf_score([T[0]] * 9, nu, u, p, n)

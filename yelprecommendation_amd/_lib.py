@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
-ENGINE_VERSION = 11
+ENGINE_VERSION = 12
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -32,6 +32,8 @@ SIGNATURES = {
     "yr_bpr_mf_pull_step": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _f,
                             _d, _d, _d, _d, _d, _d, _d, _int, _int, _p, _i64, _p, _p, _p],
     "yr_spmm_csr": [_p, _p, _p, _p, _p, _i64, _int, _int, _p, _i64, _int, _p],
+    "yr_ngcf_score_fwd": [_p, _int, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _p, _p],
+    "yr_ngcf_score_bwd": [_p, _p, _int, _p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p],
     "yr_ngcf_dense_fwd": [_p, _p, _p, _p, _i64, _int, _p, _p],
     "yr_ngcf_dense_bwd_data": [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p],
     "yr_ngcf_dense_bwd_weight": [_p, _p, _p, _p, _i64, _int, _p, _p, _p],

@@ -85,6 +85,171 @@ __global__ __launch_bounds__(kBlock) void gemm_f32_kernel(const float* __restric
   }
 }
 
+// --------------------------------------------------------------------------- tiled f32 MFMA GEMM
+// The fast path of yr_gemm_f32 (operands 16-byte aligned, leading dimensions multiples of 4):
+// workgroup = 4 waves = a BM x BN tile of C (BM, BN in {64, 128}; each wave a quarter, 1-4 MFMA
+// tiles of 32 x 32), K walked in steps of 16.  Both operand tiles live in LDS as [k][row] (row
+// contiguous, pitch rows + 4), so an MFMA operand read is one conflict-free ds_read_b32 per lane
+// (lane (i, h): k = 2 s + h, row = i) shared by up to two MFMAs.  The next K-step is fetched from
+// global memory with 16-byte loads into registers while the MFMAs of the current one run, then
+// written to the other LDS buffer: one barrier per K-step.
+//   K-contiguous operand (A with transA = 0, B with transB = 1): lane -> (row = lane % 16 + 16 c,
+//     4 k's): 16 rows x 64 B per wave instruction, transposed into [k][row] by 4 ds_write_b32
+//     (banks 16 (lane / 16) + lane % 16: conflict-free).
+//   row-contiguous operand (transA = 1, transB = 0): lane -> (4 rows, one k): 512 B contiguous
+//     per 32 lanes, one aligned ds_write_b128.
+constexpr int kTK = 16;
+
+template <int R, bool KCONTIG>
+struct TileLoader {
+  static constexpr int P = R + 4;
+  static constexpr int NV = R / 64;                    // float4 per thread per K-step
+
+  // fetch this thread's pieces of the tile rows [r0, r0 + R) x k [k0, k0 + 16) (zero outside
+  // rows < rmax, k < kend)
+  __device__ static __forceinline__ void fetch(const float* __restrict__ X, int64_t ld, int r0, int rmax, int k0,
+                                               int kend, float4 (&v)[NV]) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (KCONTIG) {
+        const int r = r0 + (lane & 15) + 16 * (wave + 4 * j);
+        const int k = k0 + 4 * (lane >> 4);
+        if (r < rmax) {
+          const float* src = X + (int64_t)r * ld + k;
+          if (k + 3 < kend) {
+            x = *reinterpret_cast<const float4*>(src);
+          } else {
+            if (k + 0 < kend) x.x = src[0];
+            if (k + 1 < kend) x.y = src[1];
+            if (k + 2 < kend) x.z = src[2];
+          }
+        }
+      } else {
+        const int idx = threadIdx.x + j * kBlock;
+        const int r = r0 + 4 * (idx % (R / 4));
+        const int k = k0 + idx / (R / 4);
+        if (k < kend) {
+          const float* src = X + (int64_t)k * ld + r;
+          if (r + 3 < rmax) {
+            x = *reinterpret_cast<const float4*>(src);
+          } else {
+            if (r + 0 < rmax) x.x = src[0];
+            if (r + 1 < rmax) x.y = src[1];
+            if (r + 2 < rmax) x.z = src[2];
+          }
+        }
+      }
+      v[j] = x;
+    }
+  }
+
+  __device__ static __forceinline__ void stash(float* __restrict__ s, const float4 (&v)[NV]) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      if (KCONTIG) {
+        const int r = (lane & 15) + 16 * (wave + 4 * j);
+        const int k = 4 * (lane >> 4);
+        s[(k + 0) * P + r] = v[j].x;
+        s[(k + 1) * P + r] = v[j].y;
+        s[(k + 2) * P + r] = v[j].z;
+        s[(k + 3) * P + r] = v[j].w;
+      } else {
+        const int idx = threadIdx.x + j * kBlock;
+        *reinterpret_cast<float4*>(s + (idx / (R / 4)) * P + 4 * (idx % (R / 4))) = v[j];
+      }
+    }
+  }
+};
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(kBlock) void gemm_f32_tiled_kernel(const float* __restrict__ A,
+                                                                const float* __restrict__ B, float* __restrict__ C,
+                                                                int M, int N, int K, int64_t lda, int64_t ldb,
+                                                                int64_t ldc, const float* __restrict__ bias, int act,
+                                                                int atomic, int k_per_split) {
+  using LA = TileLoader<BM, !TA>;
+  using LB = TileLoader<BN, TB>;
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  __shared__ float sA[2][kTK * LA::P];
+  __shared__ float sB[2][kTK * LB::P];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int i = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+  const int kbeg = blockIdx.z * k_per_split;
+  const int kend = min(K, kbeg + k_per_split);
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  float4 va[LA::NV], vb[LB::NV];
+  LA::fetch(A, lda, m0, M, kbeg, kend, va);
+  LB::fetch(B, ldb, n0, N, kbeg, kend, vb);
+  LA::stash(sA[0], va);
+  LB::stash(sB[0], vb);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += kTK) {
+    const bool more = k0 + kTK < kend;
+    if (more) {
+      LA::fetch(A, lda, m0, M, k0 + kTK, kend, va);
+      LB::fetch(B, ldb, n0, N, k0 + kTK, kend, vb);
+    }
+    const float* a_s = sA[buf];
+    const float* b_s = sB[buf];
+#pragma unroll
+    for (int s = 0; s < kTK / 2; ++s) {
+      const int k = 2 * s + h;
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) av[a] = a_s[k * LA::P + wm + a * 32 + i];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bv[b] = b_s[k * LB::P + wn + b * 32 + i];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    if (more) {
+      LA::stash(sA[buf ^ 1], va);
+      LB::stash(sB[buf ^ 1], vb);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int col = n0 + wn + b * 32 + i;
+    if (col >= N) continue;
+    const float bvl = (bias && !atomic) ? bias[col] : 0.0f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = m0 + wm + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (row < M) {
+          float* dst = C + (int64_t)row * ldc + col;
+          if (atomic) {
+            atomicAdd(dst, acc[a][b][reg]);
+          } else {
+            float v = acc[a][b][reg] + bvl;
+            if (act == 1) v = 1.0f / (1.0f + expf(-v));
+            *dst = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 // --------------------------------------------------------------------------- element-wise pieces
 // zpre[b, :] = bias[:] + V[user[b], :]      (b_h + user_nodes(user_id), models/cdae.py:49)
 __global__ __launch_bounds__(kBlock) void cdae_hidden_init_kernel(float* __restrict__ zpre,
@@ -127,13 +292,32 @@ __global__ __launch_bounds__(kBlock) void sigmoid_bwd_kernel(float* __restrict__
 }
 
 // out[c] (+)= sum_r X[r, c]        (bias gradients)
+// Workgroup = 64 columns; wave w sums rows w, w + 4, ... (256 contiguous bytes per load, 8 loads
+// in flight), the four partial sums are combined in wave order: deterministic.
 __global__ __launch_bounds__(kBlock) void colsum_kernel(const float* __restrict__ X, int64_t rows, int64_t cols,
                                                         float* __restrict__ out, int accumulate) {
-  const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float s_part[kWavesPerBlock][kWave];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int64_t c = (int64_t)blockIdx.x * kWave + lane;
   float acc = 0.0f;
-  for (int64_t r = 0; r < rows; ++r) acc += X[r * cols + c];
-  out[c] = accumulate ? out[c] + acc : acc;
+  if (c < cols) {
+    constexpr int U = 8;
+    int64_t r = wave;
+    for (; r + (U - 1) * kWavesPerBlock < rows; r += U * kWavesPerBlock) {
+      float v[U];
+#pragma unroll
+      for (int q = 0; q < U; ++q) v[q] = X[(r + q * kWavesPerBlock) * cols + c];
+#pragma unroll
+      for (int q = 0; q < U; ++q) acc += v[q];
+    }
+    for (; r < rows; r += kWavesPerBlock) acc += X[r * cols + c];
+  }
+  s_part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < cols) {
+    const float t = ((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane];
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 // dV[user[b], :] += G[b, :]        (embedding_dense_backward of user_nodes)
@@ -233,10 +417,44 @@ extern "C" int yr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
   const int splits = (int)((K + kps - 1) / kps) > 0 ? (int)((K + kps - 1) / kps) : 1;
   const int atomic = (splits > 1 || accumulate) ? 1 : 0;
   if (atomic && (bias || act)) return YR_ERR_BADARG;            // fused epilogue only on a plain store
+  hipStream_t st = (hipStream_t)stream;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
+                       lda % 4 == 0 && ldb % 4 == 0;
+  if (aligned) {
+    // largest tile that still gives every CU about eight workgroups; shrink along the dimension
+    // with more tiles first (the other operand keeps its reuse)
+    int bm = 128, bn = 128;
+    auto blocks = [&](int m, int n) { return ((M + m - 1) / m) * ((N + n - 1) / n) * (int64_t)splits; };
+    const int64_t minb = 2048;                 // measured: ~8 workgroups per CU hide the fill latency best
+    if (blocks(bm, bn) < minb) {
+      if ((M + 127) / 128 >= (N + 127) / 128) bm = 64; else bn = 64;
+      if (blocks(bm, bn) < minb) bm = bn = 64;
+    }
+    const dim3 grid((unsigned)((M + bm - 1) / bm), (unsigned)((N + bn - 1) / bn), (unsigned)splits);
+    if (grid.y > 65535 || grid.z > 65535) return YR_ERR_BADARG;
+#define YR_GEMM_LAUNCH(BM, BN, TA, TB)                                                                          \
+  hipLaunchKernelGGL((gemm_f32_tiled_kernel<BM, BN, TA, TB>), grid, dim3(kBlock), 0, st, A, B, C, (int)M, (int)N, \
+                     (int)K, lda, ldb, ldc, bias, act, atomic, kps)
+#define YR_GEMM_TRANS(BM, BN)                                        \
+  do {                                                               \
+    if (transA) {                                                    \
+      if (transB) YR_GEMM_LAUNCH(BM, BN, true, true); else YR_GEMM_LAUNCH(BM, BN, true, false);   \
+    } else {                                                         \
+      if (transB) YR_GEMM_LAUNCH(BM, BN, false, true); else YR_GEMM_LAUNCH(BM, BN, false, false); \
+    }                                                                \
+  } while (0)
+    if (bm == 128 && bn == 128) YR_GEMM_TRANS(128, 128);
+    else if (bm == 64 && bn == 128) YR_GEMM_TRANS(64, 128);
+    else if (bm == 128 && bn == 64) YR_GEMM_TRANS(128, 64);
+    else YR_GEMM_TRANS(64, 64);
+#undef YR_GEMM_TRANS
+#undef YR_GEMM_LAUNCH
+    return launch_status();
+  }
   const dim3 grid((unsigned)((N + kGemmTile - 1) / kGemmTile), (unsigned)((M + kGemmTile - 1) / kGemmTile),
                   (unsigned)splits);
   if (grid.y > 65535 || grid.z > 65535) return YR_ERR_BADARG;
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, A, B, C, (int)M, (int)N, (int)K,
+  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(kBlock), 0, st, A, B, C, (int)M, (int)N, (int)K,
                      lda, ldb, ldc, transA ? 1 : 0, transB ? 1 : 0, bias, act, atomic, kps);
   return launch_status();
 }
@@ -280,7 +498,7 @@ extern "C" int yr_colsum(const float* X, int64_t rows, int64_t cols, float* out,
   if (rows < 0 || cols < 0) return YR_ERR_BADARG;
   if (cols == 0) return 0;
   if (!out || (rows > 0 && !X)) return YR_ERR_BADARG;
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((cols + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((cols + kWave - 1) / kWave)), dim3(kBlock), 0,
                      (hipStream_t)stream, X, rows, cols, out, accumulate);
   return launch_status();
 }

@@ -8,7 +8,7 @@
 //
 //   yr_spmm_csr               Z = L X  (or Z += L X)   HBM/cache bound gather, pull form: every
 //                             output row is owned by one wave (16-byte loads, 64/(D/4) neighbours
-//                             per pass, 4 passes in flight), very long rows by a whole workgroup
+//                             per pass, 8 passes in flight, next round's indices prefetched), very long rows by a whole workgroup
 //   yr_ngcf_dense_fwd         E' = lrelu([Z+E | E*Z] . [W1 | W2]^T)            v_mfma_f32_32x32x2_f32
 //   yr_ngcf_dense_bwd_data    dP = dE' * lrelu'(E');  [dA | dH] = dP . [W1 | W2];
 //                             dZ = dA + dH*E;  dE += dA + dH*Z                 (MFMA + fused epilogue)
@@ -25,28 +25,45 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 __device__ __forceinline__ float4 ngcf_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // --------------------------------------------------------------------------- SpMM
-constexpr int kSpmmUnroll = 4;
+constexpr int kSpmmUnroll = 8;
 constexpr int kSpmmHeavyBlocks = 256;
 
+// One lane group's share of a CSR row: neighbours lo+first, lo+first+step, ...  The column/value
+// pairs of the NEXT round are fetched before this round's rows are gathered (two dependent
+// latencies per round otherwise), and slots past the row end issue no row load at all.
 template <int D>
 __device__ __forceinline__ void spmm_accumulate(const int32_t* __restrict__ col, const float* __restrict__ val,
                                                 const float* __restrict__ X, int lo, int hi, int first, int step,
                                                 int l, float4& acc) {
+  int c[kSpmmUnroll];
+  float w[kSpmmUnroll];
+#pragma unroll
+  for (int q = 0; q < kSpmmUnroll; ++q) {
+    const int idx = lo + first + q * step;
+    const bool ok = idx < hi;
+    c[q] = ok ? col[idx] : -1;
+    w[q] = ok ? val[idx] : 0.0f;
+  }
   for (int base = lo; base < hi; base += step * kSpmmUnroll) {
     float4 r[kSpmmUnroll];
-    float w[kSpmmUnroll];
+    float wc[kSpmmUnroll];
 #pragma unroll
     for (int q = 0; q < kSpmmUnroll; ++q) {
-      const int idx = base + first + q * step;
+      wc[q] = w[q];
+      r[q] = c[q] >= 0 ? ngcf_ld4(X + (int64_t)c[q] * D + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int nbase = base + step * kSpmmUnroll;
+#pragma unroll
+    for (int q = 0; q < kSpmmUnroll; ++q) {
+      const int idx = nbase + first + q * step;
       const bool ok = idx < hi;
-      const int c = ok ? col[idx] : 0;
+      c[q] = ok ? col[idx] : -1;
       w[q] = ok ? val[idx] : 0.0f;
-      r[q] = ngcf_ld4(X + (int64_t)c * D + 4 * l);
     }
 #pragma unroll
     for (int q = 0; q < kSpmmUnroll; ++q) {
-      acc.x = fmaf(w[q], r[q].x, acc.x); acc.y = fmaf(w[q], r[q].y, acc.y);
-      acc.z = fmaf(w[q], r[q].z, acc.z); acc.w = fmaf(w[q], r[q].w, acc.w);
+      acc.x = fmaf(wc[q], r[q].x, acc.x); acc.y = fmaf(wc[q], r[q].y, acc.y);
+      acc.z = fmaf(wc[q], r[q].z, acc.z); acc.w = fmaf(wc[q], r[q].w, acc.w);
     }
   }
 }
@@ -114,12 +131,114 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int32_t* __restr
   }
 }
 
+// --------------------------------------------------------------------------- layer-sum scoring
+// bpr_forward's tail (reference models/ngcf.py:44-58): the K+1 layer outputs are concatenated and
+// the score is the dot product of the user's and the item's concatenated rows, i.e. the SUM over
+// layers of per-layer dot products.  One launch scores positives and negatives over all layers
+// (one lane group per triplet, 16 bytes per lane, every layer's three rows in flight at once);
+// one launch scatter-adds the gradient of every layer buffer (float atomics, like index_add_).
+struct LayerPtrs { const float* p[YR_NGCF_MAX_LAYERS]; };
+struct LayerGradPtrs { float* p[YR_NGCF_MAX_LAYERS]; };
+
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) {
+  return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
+}
+
+template <int D, bool NEG>
+__global__ __launch_bounds__(kBlock) void ngcf_score_kernel(LayerPtrs L, int n_layers,
+                                                            const int64_t* __restrict__ user,
+                                                            const int64_t* __restrict__ pos,
+                                                            const int64_t* __restrict__ neg, int64_t B,
+                                                            int64_t num_users, int64_t num_items,
+                                                            float* __restrict__ out_pos, float* __restrict__ out_neg,
+                                                            int32_t* __restrict__ err_flag) {
+  constexpr int LPR = D / 4, GPW = kWave / LPR;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int grp = lane / LPR, l = lane % LPR;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * GPW;
+  int bad = 0;
+  for (int64_t base = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * GPW; base < B; base += stride) {
+    const int64_t b = base + grp;
+    int64_t u = 0, p = 0, n = 0;
+    bool ok = b < B;
+    if (ok) {
+      u = user[b]; p = pos[b]; n = NEG ? neg[b] : 0;
+      if (u < 0 || u >= num_users) { bad |= YR_FLAG_BAD_USER; ok = false; }
+      if (p < 0 || p >= num_items || n < 0 || n >= num_items) { bad |= YR_FLAG_BAD_ITEM; ok = false; }
+    }
+    float sp = 0.0f, sn = 0.0f;
+    if (ok) {
+      const int64_t ou = u * D + 4 * l, op = (num_users + p) * D + 4 * l, on = (num_users + n) * D + 4 * l;
+#pragma unroll 4
+      for (int k = 0; k < n_layers; ++k) {
+        const float* E = L.p[k];
+        const float4 ru = ngcf_ld4(E + ou), rp = ngcf_ld4(E + op);
+        sp += dot4(ru, rp);
+        if (NEG) sn += dot4(ru, ngcf_ld4(E + on));
+      }
+    }
+    sp = group_sum<LPR>(sp);
+    if (NEG) sn = group_sum<LPR>(sn);
+    if (l == 0 && b < B) {
+      out_pos[b] = sp;
+      if (NEG) out_neg[b] = sn;
+    }
+  }
+  if (bad && err_flag) atomicOr(err_flag, bad);
+}
+
+// Lane l of a group owns dims l, l + LPR, l + 2 LPR, l + 3 LPR here (not 4 consecutive ones): every
+// atomic instruction then covers LPR consecutive floats per row, which the memory pipeline
+// coalesces into whole 64-byte requests (the 16-byte-strided form ran at a third of the rate).
+template <int D, bool NEG>
+__global__ __launch_bounds__(kBlock) void ngcf_score_bwd_kernel(LayerPtrs L, LayerGradPtrs G, int n_layers,
+                                                                const int64_t* __restrict__ user,
+                                                                const int64_t* __restrict__ pos,
+                                                                const int64_t* __restrict__ neg,
+                                                                const float* __restrict__ gpos,
+                                                                const float* __restrict__ gneg, int64_t B,
+                                                                int64_t num_users, int64_t num_items,
+                                                                int32_t* __restrict__ err_flag) {
+  constexpr int LPR = D / 4, GPW = kWave / LPR;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int grp = lane / LPR, l = lane % LPR;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * GPW;
+  int bad = 0;
+  for (int64_t base = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * GPW; base < B; base += stride) {
+    const int64_t b = base + grp;
+    if (b >= B) continue;
+    const int64_t u = user[b], p = pos[b], n = NEG ? neg[b] : 0;
+    if (u < 0 || u >= num_users) { bad |= YR_FLAG_BAD_USER; continue; }
+    if (p < 0 || p >= num_items || n < 0 || n >= num_items) { bad |= YR_FLAG_BAD_ITEM; continue; }
+    const float gp = gpos[b], gn = NEG ? gneg[b] : 0.0f;
+    const int64_t ou = u * D + l, op = (num_users + p) * D + l, on = (num_users + n) * D + l;
+#pragma unroll 2
+    for (int k = 0; k < n_layers; ++k) {
+      const float* E = L.p[k];
+      float* dE = G.p[k];
+      float ru[4], rp[4], rn[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ru[j] = E[ou + j * LPR];
+        rp[j] = E[op + j * LPR];
+        rn[j] = NEG ? E[on + j * LPR] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        atomicAdd(dE + ou + j * LPR, NEG ? fmaf(gn, rn[j], gp * rp[j]) : gp * rp[j]);
+        atomicAdd(dE + op + j * LPR, gp * ru[j]);
+        if (NEG) atomicAdd(dE + on + j * LPR, gn * ru[j]);
+      }
+    }
+  }
+  if (bad && err_flag) atomicOr(err_flag, bad);
+}
+
 // --------------------------------------------------------------------------- dense part, MFMA
 // Operand convention of the f32 MFMA used throughout (see csrc/eval_gemm.hip): for a 32-row
 // operand, lane (i = lane & 31, h = lane >> 5) holds dims [h*K/2, (h+1)*K/2) of row i — the two
 // k-slots of each v_mfma_f32_32x32x2_f32 step are mapped to the two halves of the K range.
 // Output: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
-constexpr int kDenseRows = 128;   // rows per workgroup (32 per wave)
 constexpr float kSlope = 0.01f;   // nn.functional.leaky_relu default (models/ngcf.py:72)
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -127,27 +246,55 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 
+// The 32-row operand tiles are fetched with coalesced 16-byte loads (whole rows per lane group) and
+// handed to the MFMA register layout through a wave-private LDS tile (pitch D+4: conflict-free
+// ds_read_b128); one wave per workgroup, so staging and MFMA phases of different workgroups on a
+// SIMD overlap.  (Loading the register layout straight from global memory touches every 128-byte
+// line with 8 separate instructions and thrashes the 32 KiB L1.)
 template <int D>
-__global__ __launch_bounds__(kBlock) void ngcf_dense_fwd_kernel(const float* __restrict__ E,
-                                                                const float* __restrict__ Z,
-                                                                const float* __restrict__ W1,
-                                                                const float* __restrict__ W2, int n,
-                                                                float* __restrict__ Eout) {
+struct DenseTile {
+  static constexpr int PITCH = D + 4;
+  static constexpr int FLOATS = 32 * PITCH;
+  static constexpr int LPR = D / 4;          // lanes per staged row
+  static constexpr int RPI = kWave / LPR;    // rows per load instruction
+};
+
+template <int D>
+__global__ __launch_bounds__(kWave) void ngcf_dense_fwd_kernel(const float* __restrict__ E,
+                                                               const float* __restrict__ Z,
+                                                               const float* __restrict__ W1,
+                                                               const float* __restrict__ W2, int n,
+                                                               float* __restrict__ Eout) {
+  using T = DenseTile<D>;
   constexpr int HALF = D / 2;
   constexpr int CT = (D + 31) / 32;          // 32-column output tiles
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  __shared__ float s_a[T::FLOATS];
+  __shared__ float s_h[T::FLOATS];
+  const int lane = threadIdx.x;
   const int i = lane & 31, h = lane >> 5;
-  const int row = blockIdx.x * kDenseRows + wave * 32 + i;
+  const int64_t row0 = (int64_t)blockIdx.x * 32;
+  {
+    const int c4 = (lane % T::LPR) * 4;
+#pragma unroll
+    for (int rr = 0; rr < 32 / T::RPI; ++rr) {
+      const int r = rr * T::RPI + lane / T::LPR;
+      float4 e = make_float4(0.f, 0.f, 0.f, 0.f), z = e;
+      if (row0 + r < n) {
+        e = ngcf_ld4(E + (row0 + r) * D + c4);
+        z = ngcf_ld4(Z + (row0 + r) * D + c4);
+      }
+      *reinterpret_cast<float4*>(s_a + r * T::PITCH + c4) = make_float4(z.x + e.x, z.y + e.y, z.z + e.z, z.w + e.w);
+      *reinterpret_cast<float4*>(s_h + r * T::PITCH + c4) = make_float4(e.x * z.x, e.y * z.y, e.z * z.z, e.w * z.w);
+    }
+  }
+  __syncthreads();
   float aA[HALF], aH[HALF];
 #pragma unroll
   for (int q = 0; q < HALF / 4; ++q) {
-    float4 e = make_float4(0.f, 0.f, 0.f, 0.f), z = e;
-    if (row < n) {
-      e = ngcf_ld4(E + (int64_t)row * D + h * HALF + 4 * q);
-      z = ngcf_ld4(Z + (int64_t)row * D + h * HALF + 4 * q);
-    }
-    aA[4 * q + 0] = z.x + e.x; aA[4 * q + 1] = z.y + e.y; aA[4 * q + 2] = z.z + e.z; aA[4 * q + 3] = z.w + e.w;
-    aH[4 * q + 0] = e.x * z.x; aH[4 * q + 1] = e.y * z.y; aH[4 * q + 2] = e.z * z.z; aH[4 * q + 3] = e.w * z.w;
+    const float4 a = *reinterpret_cast<const float4*>(s_a + i * T::PITCH + h * HALF + 4 * q);
+    const float4 m = *reinterpret_cast<const float4*>(s_h + i * T::PITCH + h * HALF + 4 * q);
+    aA[4 * q + 0] = a.x; aA[4 * q + 1] = a.y; aA[4 * q + 2] = a.z; aA[4 * q + 3] = a.w;
+    aH[4 * q + 0] = m.x; aH[4 * q + 1] = m.y; aH[4 * q + 2] = m.z; aH[4 * q + 3] = m.w;
   }
 #pragma unroll
   for (int t = 0; t < CT; ++t) {
@@ -171,10 +318,10 @@ __global__ __launch_bounds__(kBlock) void ngcf_dense_fwd_kernel(const float* __r
     if (j < D) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        const int r = blockIdx.x * kDenseRows + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        const int64_t r = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
         if (r < n) {
           const float p = acc[reg];
-          Eout[(int64_t)r * D + j] = p > 0.0f ? p : kSlope * p;
+          Eout[r * D + j] = p > 0.0f ? p : kSlope * p;
         }
       }
     }
@@ -184,25 +331,38 @@ __global__ __launch_bounds__(kBlock) void ngcf_dense_fwd_kernel(const float* __r
 // dP = dEout * lrelu'(Eout);  [dA | dH] = dP . [W1 | W2]  (W1T/W2T = transposed weights, [in, out]);
 // dZ = dA + dH * E;  dE += dA + dH * Z
 template <int D>
-__global__ __launch_bounds__(kBlock) void ngcf_dense_bwd_data_kernel(
+__global__ __launch_bounds__(kWave) void ngcf_dense_bwd_data_kernel(
     const float* __restrict__ dEout, const float* __restrict__ Eout, const float* __restrict__ E,
     const float* __restrict__ Z, const float* __restrict__ W1T, const float* __restrict__ W2T, int n,
     float* __restrict__ dZ, float* __restrict__ dE) {
+  using T = DenseTile<D>;
   constexpr int HALF = D / 2;
   constexpr int CT = (D + 31) / 32;
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  __shared__ float s_p[T::FLOATS];
+  const int lane = threadIdx.x;
   const int i = lane & 31, h = lane >> 5;
-  const int row = blockIdx.x * kDenseRows + wave * 32 + i;
+  const int64_t row0 = (int64_t)blockIdx.x * 32;
+  {
+    const int c4 = (lane % T::LPR) * 4;
+#pragma unroll
+    for (int rr = 0; rr < 32 / T::RPI; ++rr) {
+      const int r = rr * T::RPI + lane / T::LPR;
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f), o = g;
+      if (row0 + r < n) {
+        g = ngcf_ld4(dEout + (row0 + r) * D + c4);
+        o = ngcf_ld4(Eout + (row0 + r) * D + c4);
+      }
+      *reinterpret_cast<float4*>(s_p + r * T::PITCH + c4) =
+          make_float4(o.x > 0.0f ? g.x : kSlope * g.x, o.y > 0.0f ? g.y : kSlope * g.y,
+                      o.z > 0.0f ? g.z : kSlope * g.z, o.w > 0.0f ? g.w : kSlope * g.w);
+    }
+  }
+  __syncthreads();
   float a[HALF];
 #pragma unroll
   for (int q = 0; q < HALF / 4; ++q) {
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), o = g;
-    if (row < n) {
-      g = ngcf_ld4(dEout + (int64_t)row * D + h * HALF + 4 * q);
-      o = ngcf_ld4(Eout + (int64_t)row * D + h * HALF + 4 * q);
-    }
-    a[4 * q + 0] = o.x > 0.0f ? g.x : kSlope * g.x; a[4 * q + 1] = o.y > 0.0f ? g.y : kSlope * g.y;
-    a[4 * q + 2] = o.z > 0.0f ? g.z : kSlope * g.z; a[4 * q + 3] = o.w > 0.0f ? g.w : kSlope * g.w;
+    const float4 v = *reinterpret_cast<const float4*>(s_p + i * T::PITCH + h * HALF + 4 * q);
+    a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
   }
 #pragma unroll
   for (int t = 0; t < CT; ++t) {
@@ -226,9 +386,9 @@ __global__ __launch_bounds__(kBlock) void ngcf_dense_bwd_data_kernel(
     if (c < D) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        const int r = blockIdx.x * kDenseRows + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        const int64_t r = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
         if (r < n) {
-          const int64_t o = (int64_t)r * D + c;
+          const int64_t o = r * D + c;
           const float e = E[o], z = Z[o];
           dZ[o] = accA[reg] + accH[reg] * e;
           dE[o] += accA[reg] + accH[reg] * z;
@@ -259,41 +419,61 @@ __global__ __launch_bounds__(kBlock) void ngcf_dense_bwd_weight_kernel(
   __shared__ float s_h[kWRows * PITCH];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int i = lane & 31, h = lane >> 5;
-  const int row0 = blockIdx.x * kWRows;
-  for (int q = threadIdx.x; q < kWRows * D; q += kBlock) {
-    const int r = q / D, c = q % D;
-    float dp = 0.f, av = 0.f, hv = 0.f;
-    if (row0 + r < n) {
-      const int64_t o = (int64_t)(row0 + r) * D + c;
-      const float g = dEout[o], eo = Eout[o], e = E[o], z = Z[o];
-      dp = eo > 0.0f ? g : kSlope * g;
-      av = z + e;
-      hv = e * z;
-    }
-    s_dp[r * PITCH + c] = dp;
-    s_a[r * PITCH + c] = av;
-    s_h[r * PITCH + c] = hv;
-  }
-  __syncthreads();
-  for (int tile = wave; tile < NT; tile += kWavesPerBlock) {
-    const int which = tile / (RT * RT);      // 0: dW1 (A), 1: dW2 (H)
-    const int tj = (tile % (RT * RT)) / RT, tc = tile % RT;
-    const float* s_b = which ? s_h : s_a;
-    const int j = tj * 32 + i, c = tc * 32 + i;
-    f32x16 acc = zero16();
-#pragma unroll 8
-    for (int s = 0; s < kWRows / 2; ++s) {
-      const int r = h * (kWRows / 2) + s;
-      const float av = j < D ? s_dp[r * PITCH + j] : 0.0f;
-      const float bv = c < D ? s_b[r * PITCH + c] : 0.0f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-    }
-    float* out = which ? dW2 : dW1;
-    if (c < D) {
+  constexpr int TPW = (NT + kWavesPerBlock - 1) / kWavesPerBlock;   // output tiles per wave
+  f32x16 acc[TPW];
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int jj = tj * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        if (jj < D) atomicAdd(out + jj * D + c, acc[reg]);
+  for (int t = 0; t < TPW; ++t) acc[t] = zero16();
+  // persistent over row chunks: the 2 D^2 partial sums stay in registers until the end, so the
+  // float atomics on dW scale with the grid, not with n
+  for (int64_t row0 = (int64_t)blockIdx.x * kWRows; row0 < n; row0 += (int64_t)gridDim.x * kWRows) {
+    __syncthreads();
+    for (int q = threadIdx.x; q < kWRows * D; q += kBlock) {
+      const int r = q / D, c = q % D;
+      float dp = 0.f, av = 0.f, hv = 0.f;
+      if (row0 + r < n) {
+        const int64_t o = (int64_t)(row0 + r) * D + c;
+        const float g = dEout[o], eo = Eout[o], e = E[o], z = Z[o];
+        dp = eo > 0.0f ? g : kSlope * g;
+        av = z + e;
+        hv = e * z;
+      }
+      s_dp[r * PITCH + c] = dp;
+      s_a[r * PITCH + c] = av;
+      s_h[r * PITCH + c] = hv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tile = wave + t * kWavesPerBlock;
+      if (tile < NT) {
+        const int which = tile / (RT * RT);      // 0: dW1 (A), 1: dW2 (H)
+        const int tj = (tile % (RT * RT)) / RT, tc = tile % RT;
+        const float* s_b = which ? s_h : s_a;
+        const int j = tj * 32 + i, c = tc * 32 + i;
+#pragma unroll 8
+        for (int s = 0; s < kWRows / 2; ++s) {
+          const int r = h * (kWRows / 2) + s;
+          const float av = j < D ? s_dp[r * PITCH + j] : 0.0f;
+          const float bv = c < D ? s_b[r * PITCH + c] : 0.0f;
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tile = wave + t * kWavesPerBlock;
+    if (tile < NT) {
+      const int which = tile / (RT * RT);
+      const int tj = (tile % (RT * RT)) / RT, tc = tile % RT;
+      const int c = tc * 32 + i;
+      float* out = which ? dW2 : dW1;
+      if (c < D) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int jj = tj * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          if (jj < D) atomicAdd(out + jj * D + c, acc[t][reg]);
+        }
       }
     }
   }
@@ -321,7 +501,7 @@ extern "C" int yr_spmm_csr(const int32_t* rowptr, const int32_t* col, const floa
   if (n_heavy > 0 && !heavy_rows) return YR_ERR_BADARG;
   if (heavy_threshold <= 0 || n_heavy == 0) heavy_threshold = n_heavy > 0 ? 256 : 0x7fffffff;
   int light = (int)((n + kWavesPerBlock - 1) / kWavesPerBlock);
-  if (light > 4096) light = 4096;
+  if (light > 65536) light = 65536;                    // one row per wave; the row loop covers larger graphs
   const int grid = kSpmmHeavyBlocks + light;
   hipStream_t s = (hipStream_t)stream;
   if (accumulate) {
@@ -334,13 +514,70 @@ extern "C" int yr_spmm_csr(const int32_t* rowptr, const int32_t* col, const floa
   return launch_status();
 }
 
+static int score_grid(int64_t B, int D) {
+  const int64_t per_block = (int64_t)kWavesPerBlock * (kWave / (D / 4));
+  int64_t g = (B + per_block - 1) / per_block;
+  return (int)(g > 8192 ? 8192 : g);
+}
+
+extern "C" int yr_ngcf_score_fwd(const float* const* layers, int n_layers, const int64_t* user, const int64_t* pos,
+                                 const int64_t* neg, int64_t B, int D, int64_t num_users, int64_t num_items,
+                                 float* out_pos, float* out_neg, int32_t* err_flag, void* stream) {
+  if (B < 0 || num_users <= 0 || num_items <= 0 || n_layers <= 0 || n_layers > YR_NGCF_MAX_LAYERS) return YR_ERR_BADARG;
+  if (D != 16 && D != 32 && D != 64 && D != 128) return YR_ERR_UNSUPPORTED;
+  if (B == 0) return 0;
+  if (!layers || !user || !pos || !out_pos || (neg != nullptr) != (out_neg != nullptr)) return YR_ERR_BADARG;
+  LayerPtrs L{};
+  for (int k = 0; k < n_layers; ++k) {
+    if (!layers[k]) return YR_ERR_BADARG;
+    L.p[k] = layers[k];
+  }
+  const int grid = score_grid(B, D);
+  hipStream_t s = (hipStream_t)stream;
+  if (neg) {
+    YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((ngcf_score_kernel<kD, true>), dim3(grid), dim3(kBlock), 0, s, L, n_layers,
+                                           user, pos, neg, B, num_users, num_items, out_pos, out_neg, err_flag));
+  } else {
+    YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((ngcf_score_kernel<kD, false>), dim3(grid), dim3(kBlock), 0, s, L, n_layers,
+                                           user, pos, neg, B, num_users, num_items, out_pos, out_neg, err_flag));
+  }
+  return launch_status();
+}
+
+extern "C" int yr_ngcf_score_bwd(const float* const* layers, float* const* dlayers, int n_layers, const int64_t* user,
+                                 const int64_t* pos, const int64_t* neg, const float* gpos, const float* gneg,
+                                 int64_t B, int D, int64_t num_users, int64_t num_items, int32_t* err_flag,
+                                 void* stream) {
+  if (B < 0 || num_users <= 0 || num_items <= 0 || n_layers <= 0 || n_layers > YR_NGCF_MAX_LAYERS) return YR_ERR_BADARG;
+  if (D != 16 && D != 32 && D != 64 && D != 128) return YR_ERR_UNSUPPORTED;
+  if (B == 0) return 0;
+  if (!layers || !dlayers || !user || !pos || !gpos || (neg != nullptr) != (gneg != nullptr)) return YR_ERR_BADARG;
+  LayerPtrs L{};
+  LayerGradPtrs G{};
+  for (int k = 0; k < n_layers; ++k) {
+    if (!layers[k] || !dlayers[k]) return YR_ERR_BADARG;
+    L.p[k] = layers[k];
+    G.p[k] = dlayers[k];
+  }
+  const int grid = score_grid(B, D);
+  hipStream_t s = (hipStream_t)stream;
+  if (neg) {
+    YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((ngcf_score_bwd_kernel<kD, true>), dim3(grid), dim3(kBlock), 0, s, L, G,
+                                           n_layers, user, pos, neg, gpos, gneg, B, num_users, num_items, err_flag));
+  } else {
+    YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((ngcf_score_bwd_kernel<kD, false>), dim3(grid), dim3(kBlock), 0, s, L, G,
+                                           n_layers, user, pos, neg, gpos, gneg, B, num_users, num_items, err_flag));
+  }
+  return launch_status();
+}
+
 extern "C" int yr_ngcf_dense_fwd(const float* E, const float* Z, const float* W1, const float* W2, int64_t n, int D,
                                  float* Eout, void* stream) {
   if (n < 0 || n > 0x7fffffff) return YR_ERR_BADARG;
   if (n == 0) return 0;
   if (!E || !Z || !W1 || !W2 || !Eout) return YR_ERR_BADARG;
-  const int grid = (int)((n + kDenseRows - 1) / kDenseRows);
-  YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((ngcf_dense_fwd_kernel<kD>), dim3(grid), dim3(kBlock), 0,
+  const int grid = (int)((n + 31) / 32);
+  YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((ngcf_dense_fwd_kernel<kD>), dim3(grid), dim3(kWave), 0,
                                          (hipStream_t)stream, E, Z, W1, W2, (int)n, Eout));
   return launch_status();
 }
@@ -351,8 +588,8 @@ extern "C" int yr_ngcf_dense_bwd_data(const float* dEout, const float* Eout, con
   if (n < 0 || n > 0x7fffffff) return YR_ERR_BADARG;
   if (n == 0) return 0;
   if (!dEout || !Eout || !E || !Z || !W1T || !W2T || !dZ || !dE) return YR_ERR_BADARG;
-  const int grid = (int)((n + kDenseRows - 1) / kDenseRows);
-  YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((ngcf_dense_bwd_data_kernel<kD>), dim3(grid), dim3(kBlock), 0,
+  const int grid = (int)((n + 31) / 32);
+  YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((ngcf_dense_bwd_data_kernel<kD>), dim3(grid), dim3(kWave), 0,
                                          (hipStream_t)stream, dEout, Eout, E, Z, W1T, W2T, (int)n, dZ, dE));
   return launch_status();
 }
@@ -362,9 +599,11 @@ extern "C" int yr_ngcf_dense_bwd_weight(const float* dEout, const float* Eout, c
   if (n < 0 || n > 0x7fffffff) return YR_ERR_BADARG;
   if (n == 0) return 0;
   if (!dEout || !Eout || !E || !Z || !dW1 || !dW2) return YR_ERR_BADARG;
-  YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((ngcf_dense_bwd_weight_kernel<kD>),
-                                         dim3((unsigned)((n + WChunk<kD>::ROWS - 1) / WChunk<kD>::ROWS)),
-                                         dim3(kBlock), 0, (hipStream_t)stream, dEout, Eout, E, Z, (int)n, dW1,
-                                         dW2));
+  YR_NGCF_DISPATCH(D, {
+    const int64_t chunks = (n + WChunk<kD>::ROWS - 1) / WChunk<kD>::ROWS;
+    const int64_t per_block = (chunks + 511) / 512;            // <= 512 workgroups, equal shares
+    hipLaunchKernelGGL((ngcf_dense_bwd_weight_kernel<kD>), dim3((unsigned)((chunks + per_block - 1) / per_block)),
+                       dim3(kBlock), 0, (hipStream_t)stream, dEout, Eout, E, Z, (int)n, dW1, dW2);
+  });
   return launch_status();
 }

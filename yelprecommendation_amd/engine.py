@@ -172,6 +172,48 @@ def spmm_csr(graph, X, out=None, accumulate=False):
     return out
 
 
+NGCF_MAX_LAYERS = 8
+
+
+def _ptr_array(tensors, what):
+    import ctypes
+    if not 0 < len(tensors) <= NGCF_MAX_LAYERS:
+        raise EngineError(f"{what}: between 1 and {NGCF_MAX_LAYERS} layer buffers")
+    return (ctypes.c_void_p * len(tensors))(*[_dev(t, torch.float32, what) for t in tensors])
+
+
+def ngcf_score(layers, num_users, user_id, pos_ids, neg_ids=None, err_flag=None):
+    """Scores of the concatenated layer embeddings (reference models/ngcf.py:44-58): returns
+    ``pos`` or ``(pos, neg)``, each the sum over layers of per-layer dot products."""
+    lib = _lib.load()
+    n, d = layers[0].shape
+    B = user_id.numel()
+    i64 = torch.int64
+    pos = torch.empty(B, dtype=torch.float32, device=layers[0].device)
+    neg = torch.empty_like(pos) if neg_ids is not None else None
+    check(lib.yr_ngcf_score_fwd(_ptr_array(layers, "layers"), len(layers), _dev(user_id, i64, "user_id"),
+                                _dev(pos_ids, i64, "pos_ids"), _dev(neg_ids, i64, "neg_ids") if neg_ids is not None else None,
+                                B, d, num_users, n - num_users, pos.data_ptr(),
+                                neg.data_ptr() if neg is not None else None,
+                                err_flag.data_ptr() if err_flag is not None else None, _stream()), "yr_ngcf_score_fwd")
+    return pos if neg is None else (pos, neg)
+
+
+def ngcf_score_backward(layers, dlayers, num_users, user_id, pos_ids, neg_ids, gpos, gneg, err_flag=None):
+    """dlayers[k] += gradient of :func:`ngcf_score` w.r.t. layers[k] (float atomics)."""
+    lib = _lib.load()
+    n, d = layers[0].shape
+    i64, f32 = torch.int64, torch.float32
+    if len(layers) != len(dlayers):
+        raise EngineError("layers / dlayers length mismatch")
+    check(lib.yr_ngcf_score_bwd(_ptr_array(layers, "layers"), _ptr_array(dlayers, "dlayers"), len(layers),
+                                _dev(user_id, i64, "user_id"), _dev(pos_ids, i64, "pos_ids"),
+                                _dev(neg_ids, i64, "neg_ids") if neg_ids is not None else None,
+                                _dev(gpos, f32, "gpos"), _dev(gneg, f32, "gneg") if neg_ids is not None else None,
+                                user_id.numel(), d, num_users, n - num_users,
+                                err_flag.data_ptr() if err_flag is not None else None, _stream()), "yr_ngcf_score_bwd")
+
+
 def ngcf_dense_fwd(E, Z, W1, W2, out=None):
     """leaky_relu((Z + E) W1^T + (E * Z) W2^T)   (reference models/ngcf.py:64-72)."""
     lib = _lib.load()

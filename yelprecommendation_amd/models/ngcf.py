@@ -44,14 +44,9 @@ class _NGCFScores(torch.autograd.Function):
         user_id = user_id.contiguous()
         pos_ids = pos_ids.contiguous()
         neg_ids = None if neg_ids is None else neg_ids.contiguous()
-        pos = neg = None
-        for E in layers:
-            # users are rows [0, num_users), items rows [num_users, N): two views of one table
-            s = engine.mf_score(E[:num_users], E[num_users:], user_id, pos_ids, err_flag=err_flag)
-            pos = s if pos is None else _iadd(pos, s)
-            if neg_ids is not None:
-                s = engine.mf_score(E[:num_users], E[num_users:], user_id, neg_ids, err_flag=err_flag)
-                neg = s if neg is None else _iadd(neg, s)
+        # users are rows [0, num_users), items rows [num_users, N) of every layer buffer
+        res = engine.ngcf_score(layers, num_users, user_id, pos_ids, neg_ids, err_flag=err_flag)
+        pos, neg = res if neg_ids is not None else (res, None)
         ctx.graph, ctx.num_users, ctx.K, ctx.err_flag = graph, num_users, K, err_flag
         ctx.has_neg = neg_ids is not None
         ctx.save_for_backward(user_id, pos_ids, neg_ids if neg_ids is not None else pos_ids,
@@ -71,14 +66,9 @@ class _NGCFScores(torch.autograd.Function):
         W1s, W2s = weights[:K], weights[K:]
         gpos = gpos.contiguous()
         # gradient of every layer buffer from the scores (dense scatter-add, like index_add_)
-        dlayers = []
-        for E in layers:
-            d = _zero_like(E)
-            engine.mf_score_backward(E[:nu], E[nu:], user_id, pos_ids, gpos, d[:nu], d[nu:], err_flag=ctx.err_flag)
-            if ctx.has_neg:
-                engine.mf_score_backward(E[:nu], E[nu:], user_id, neg_ids, gneg.contiguous(), d[:nu], d[nu:],
-                                         err_flag=ctx.err_flag)
-            dlayers.append(d)
+        dlayers = [_zero_like(E) for E in layers]
+        engine.ngcf_score_backward(layers, dlayers, nu, user_id, pos_ids, neg_ids if ctx.has_neg else None,
+                                   gpos, gneg.contiguous() if ctx.has_neg else None, err_flag=ctx.err_flag)
         dW1s, dW2s = [None] * K, [None] * K
         for k in range(K - 1, -1, -1):
             dW1s[k], dW2s[k] = _zero_like(W1s[k]), _zero_like(W2s[k])
