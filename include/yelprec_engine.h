@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 12
+#define YR_ENGINE_VERSION 13
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -287,8 +287,9 @@ int yr_topk_masked(const float *scores, int64_t nrows, int64_t ncols, int64_t ro
  *   and divides by len(actual); DCG scans positions 1..min(len(actual), k) only)
  *   topk [n, k] int64 (e.g. from yr_mf_eval_topk), pos_ptr [n+1] / pos_idx: the held-out items of
  *   each row in their ORIGINAL order (AP depends on it).
- *   out[0..3] = precision@k, recall@k, MAP@k, NDCG@k (float64), out[4] = users with non-empty
- *   `actual`.  workspace: yr_rank_metrics_workspace_bytes(n) bytes.
+ *   out (10 float64): [0..3] = precision@k, recall@k, MAP@k, NDCG@k, [4] = users with non-empty
+ *   `actual`, [5..8] = the four un-normalised sums and [9] = n (a user-sharded evaluation sums
+ *   [4..9] over ranks and divides once).  workspace: yr_rank_metrics_workspace_bytes(n) bytes.
  * ------------------------------------------------------------------------- */
 int64_t yr_rank_metrics_workspace_bytes(int64_t n);
 int yr_rank_metrics(const int64_t *topk, int64_t n, int k, const int64_t *pos_ptr, const int64_t *pos_idx,

@@ -131,3 +131,66 @@ def _nccl_worker(rank, world, port, out_dir):
 def test_exchange_over_rccl_single_rank(tmp_path, device):
     mp.spawn(_nccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     assert open(os.path.join(str(tmp_path), "ok")).read() == "True"
+
+
+# ------------------------------------------------------------------------------------------------
+# The user-sharded MFTrainer (2 ranks on cuda:0 over gloo) against the single-process trainer
+def _trainer_problem(tmp):
+    import pandas as pd
+    from yelprecommendation_amd.data.synthetic import make_frame
+    from yelprecommendation_amd.data.datasets.mf_data_pipeline import MFDataPipeline
+    from yelprecommendation_amd.data.datasets.mf_dataset import MFDataset
+    from yelprecommendation_amd.utils import make_config
+    cfg = make_config("MF", embed_size=32, lr=5e-3, batch_size=512, epochs=3, device="cuda", model_dir=tmp,
+                      seed=42, top_n=10, patience=5, best_metric="recall")
+    pipe = MFDataPipeline(cfg)
+    df = make_frame(150, 120, 14.0)
+    pipe._load_df = lambda: df
+    df = pipe.preprocess()
+    train_data, valid_data, valid_eval, test_eval = pipe.split(df)
+    return cfg, pipe, MFDataset(train_data, num_items=pipe.num_items), MFDataset(valid_data, num_items=pipe.num_items), \
+        valid_eval, test_eval
+
+
+def _run_trainer(tmp):
+    from torch.utils.data import DataLoader
+    from yelprecommendation_amd.trainers.mf_trainer import MFTrainer
+    from yelprecommendation_amd.utils import set_seed
+    cfg, pipe, train_ds, valid_ds, valid_eval, test_eval = _trainer_problem(tmp)
+    set_seed(cfg.seed)
+    trainer = MFTrainer(cfg, pipe.num_items, pipe.num_users)
+    trainer.run(DataLoader(train_ds, batch_size=cfg.batch_size, shuffle=True),
+                DataLoader(valid_ds, batch_size=cfg.batch_size, shuffle=True), valid_eval)
+    trainer.load_best_model()
+    return trainer, trainer.evaluate(test_eval, 'test')
+
+
+def _trainer_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    trainer, metrics = _run_trainer(os.path.join(out_dir, "sharded"))
+    assert trainer.world_size == world and trainer.shard.rank == rank
+    np.savez(os.path.join(out_dir, f"trainer_rank{rank}.npz"), metrics=np.asarray(metrics),
+             U=trainer.model.user_embedding.weight.detach().cpu().numpy(),
+             I=trainer.model.item_embedding.weight.detach().cpu().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_sharded_trainer_matches_single_process(tmp_path, device):
+    """MFTrainer.run + load_best_model + evaluate under a 2-rank group == the same calls in one
+    process: tables to float rounding (summation order of the item gradient), metrics identical
+    on every rank and within 1e-3 of the single-process ones."""
+    world = 2
+    os.makedirs(os.path.join(str(tmp_path), "sharded"), exist_ok=True)
+    mp.spawn(_trainer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    single, want = _run_trainer(os.path.join(str(tmp_path), "single"))
+    outs = [np.load(os.path.join(str(tmp_path), f"trainer_rank{r}.npz")) for r in range(world)]
+    np.testing.assert_array_equal(outs[0]["metrics"], outs[1]["metrics"])
+    np.testing.assert_allclose(outs[0]["metrics"], np.asarray(want), atol=1e-3)
+    for o in outs:
+        np.testing.assert_allclose(o["U"], single.model.user_embedding.weight.detach().cpu().numpy(),
+                                   rtol=2e-3, atol=2e-5)
+        np.testing.assert_allclose(o["I"], single.model.item_embedding.weight.detach().cpu().numpy(),
+                                   rtol=2e-3, atol=2e-5)

@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
-ENGINE_VERSION = 12
+ENGINE_VERSION = 13
 
 _p = C.c_void_p
 _i64 = C.c_int64

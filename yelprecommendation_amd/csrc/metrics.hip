@@ -88,7 +88,8 @@ __global__ __launch_bounds__(kBlock) void rank_metrics_kernel(const int64_t* __r
   }
 }
 
-// out[0..3] = precision, recall, MAP, NDCG;  out[4] = users with a non-empty actual list
+// out[0..3] = precision, recall, MAP, NDCG;  out[4] = users with a non-empty actual list;
+// out[5..8] = the four un-normalised sums, out[9] = n (what a user-sharded evaluation all-reduces)
 __global__ void rank_metrics_finalize_kernel(const double* __restrict__ partial, int nblocks, int64_t n,
                                              double* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -100,6 +101,8 @@ __global__ void rank_metrics_finalize_kernel(const double* __restrict__ partial,
   out[2] = s[2] / s[4];
   out[3] = s[3] / s[4];
   out[4] = s[4];
+  out[5] = s[0]; out[6] = s[1]; out[7] = s[2]; out[8] = s[3];
+  out[9] = (double)n;
 }
 
 }  // namespace yr

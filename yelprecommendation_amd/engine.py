@@ -446,14 +446,15 @@ def mf_recommend(U, I, users, mask_ptr, mask_idx, k, chunk_users=4096, fused=Non
 
 def rank_metrics(topk, pos_ptr, pos_idx):
     """(precision, recall, map, ndcg)@k of reference metric.py computed on the device from the top-k
-    lists ``topk [n, k]`` and the held-out items (CSR, original order).  Returns a float64[5] device
-    tensor (the 5th entry is the number of users with a non-empty list); one host sync to read it."""
+    lists ``topk [n, k]`` and the held-out items (CSR, original order).  Returns a float64[10] device
+    tensor: the four metrics, the number of users with a non-empty list, then the four un-normalised
+    sums and n (for a cross-rank reduction); one host sync to read it."""
     lib = _lib.load()
     n, k = topk.shape
     if pos_ptr.numel() != n + 1:
         raise EngineError("pos_ptr must have rows + 1 entries")
     ws = torch.empty(lib.yr_rank_metrics_workspace_bytes(n) // 8, dtype=torch.float64, device=topk.device)
-    out = torch.empty(5, dtype=torch.float64, device=topk.device)
+    out = torch.empty(10, dtype=torch.float64, device=topk.device)
     idx = pos_idx if pos_idx.numel() else torch.zeros(1, dtype=torch.int64, device=topk.device)
     check(lib.yr_rank_metrics(_dev(topk, torch.int64, "topk"), n, k, _dev(pos_ptr, torch.int64, "pos_ptr"),
                               _dev(idx, torch.int64, "pos_idx"), ws.data_ptr(), out.data_ptr(), _stream()),

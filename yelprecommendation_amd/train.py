@@ -116,8 +116,25 @@ def run(cfg, args):
     return train(cfg, args)
 
 
+def _init_distributed():
+    """One process per GPU under ``python -m torch.distributed.run`` (MF only: the interaction
+    matrix is then sharded by user, see trainers/mf_trainer.py); a plain launch stays single-GPU."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return False
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=dev)              # RCCL over xGMI
+    return True
+
+
 def main(argv=None):
     logging.basicConfig(level=logging.INFO, format="%(message)s")
+    distributed = _init_distributed()
     over = _parse_overrides(sys.argv[1:] if argv is None else argv)
     path = over.pop("config", None)
     model_name = over.pop("model_name", "MF")
@@ -125,6 +142,9 @@ def main(argv=None):
     args = build(cfg)
     trainer, metrics = run(cfg, args)
     logger.info(f"test precision/recall/map/ndcg @{cfg.top_n}: {metrics}")
+    if distributed:
+        import torch.distributed as dist
+        dist.destroy_process_group()
     return metrics
 
 

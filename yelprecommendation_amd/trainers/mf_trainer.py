@@ -15,6 +15,13 @@ Differences underneath (results equal to float rounding):
 * ``evaluate`` scores all eval users against the whole catalogue on the device with
   the train-item mask and top-k fused in, instead of a Python loop of per-user
   forward calls (mf_trainer.py:139-144).
+
+Multi-GPU (new; the reference is single-process): when ``torch.distributed`` is initialised with
+more than one rank, the interaction matrix is sharded by user.  Every rank runs the
+same script on the same seeded loaders; of each global batch it trains the triplets of the users
+it owns (``UserShard.select``), the item gradient is all-reduced inside ``BPRMFStep`` (RCCL), the
+user rows are exchanged once per epoch, ``evaluate`` scores only the rank's users and sums the
+per-user metric terms with one 6-double all-reduce, and only rank 0 writes ``best_model.pt``.
 """
 import numpy as np
 import torch
@@ -24,8 +31,17 @@ from ..bpr_step import BPRMFStep
 from ..loss import BPRLoss
 from ..metric import ranking_metrics
 from ..models.mf import MatrixFactorization
+from ..user_shard import UserShard
 from ..utils import logger
 from .base_trainer import BaseTrainer
+
+
+def _dist():
+    """torch.distributed when a multi-rank process group is up, else None."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
 
 
 def _lists_to_csr(lists):
@@ -45,6 +61,10 @@ class MFTrainer(BaseTrainer):
         self.loss = self._loss()
         self._loss_accum = torch.zeros(1, dtype=torch.float64, device=self.device)
         self._eval_cache = {}
+        dist = _dist()
+        self.world_size = dist.get_world_size() if dist else 1
+        self.rank = dist.get_rank() if dist else 0
+        self.shard = UserShard(num_users, self.world_size, self.rank)
 
     def _loss(self):
         return BPRLoss()
@@ -63,7 +83,10 @@ class MFTrainer(BaseTrainer):
                 logger.info("[Trainer] update best model...")
                 best = current
                 endurance = 0
-                torch.save(self.model.state_dict(), f'{self.cfg.model_dir}/best_model.pt')
+                if self.rank == 0:
+                    torch.save(self.model.state_dict(), f'{self.cfg.model_dir}/best_model.pt')
+                if self.world_size > 1:
+                    _dist().barrier()                      # the file is complete before anyone loads it
             else:
                 endurance += 1
                 if endurance > self.cfg.patience:
@@ -90,16 +113,29 @@ class MFTrainer(BaseTrainer):
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         sU, sI = self.optimizer.state[U], self.optimizer.state[I]
-        return BPRMFStep(U.data, I.data, lr=group["lr"], betas=group["betas"], eps=group["eps"],
+        lo, hi = self.shard.lo, self.shard.hi              # the whole table on one GPU
+        return BPRMFStep(U.data[lo:hi], I.data, lr=group["lr"], betas=group["betas"], eps=group["eps"],
                          weight_decay=group["weight_decay"],
                          optimizer="adamw" if self.optimizer._decoupled else "adam",
-                         state=dict(mU=sU["exp_avg"], vU=sU["exp_avg_sq"], mI=sI["exp_avg"], vI=sI["exp_avg_sq"],
-                                    t=sU["step"]))
+                         world_size=self.world_size,
+                         state=dict(mU=sU["exp_avg"][lo:hi], vU=sU["exp_avg_sq"][lo:hi], mI=sI["exp_avg"],
+                                    vI=sI["exp_avg_sq"], t=sU["step"]))
+
+    def _exchange_user_rows(self):
+        """Every rank receives the rows the other ranks trained (once per epoch, 8 MB in total)."""
+        dist = _dist()
+        U = self.model.user_embedding.weight.data
+        for r in range(self.world_size):
+            lo, hi = self.shard.bounds(r)
+            if hi > lo:
+                dist.broadcast(U[lo:hi], src=r)
 
     def train(self, train_dataloader) -> float:
         # reference mf_trainer.py:100-116
         self.model.train()
         step = self._fused_step()
+        if step is None and self.world_size > 1:
+            raise NotImplementedError("user-sharded training needs optimizer adam or adamw")
         if step is None:                                   # SGD: fused fwd/bwd kernel + dense update
             self._loss_accum.zero_()
             for data in train_dataloader:
@@ -108,11 +144,21 @@ class MFTrainer(BaseTrainer):
                 self.optimizer.step(zero_grad=True)
             self.model.check_indices()
             return float(self._loss_accum.item())
-        for data in train_dataloader:
-            step.step(*self._batch(data))
-        # hand the (double-buffered) user table and the step count back to the module / optimizer
         U, I = self.model.user_embedding.weight, self.model.item_embedding.weight
-        U.data = step.U
+        if self.world_size > 1:
+            for data in train_dataloader:
+                user_id, pos_item, neg_item = self._batch(data)
+                mine = [t.contiguous() for t in self.shard.select(user_id, pos_item, neg_item)]
+                step.step(*mine, global_batch=user_id.numel())
+            own = U.data[self.shard.lo:self.shard.hi]
+            if step.U.data_ptr() != own.data_ptr():
+                own.copy_(step.U)
+            self._exchange_user_rows()
+        else:
+            for data in train_dataloader:
+                step.step(*self._batch(data))
+            # hand the (double-buffered) user table back to the module
+            U.data = step.U
         self.optimizer.state[U]["step"] = self.optimizer.state[I]["step"] = step.t
         total = step.epoch_loss()
         step.check()
@@ -136,7 +182,11 @@ class MFTrainer(BaseTrainer):
         if key not in self._eval_cache:
             users = np.asarray(eval_data.index.values, dtype=np.int64)
             pos = [list(x) for x in eval_data['pos_items']]
-            mask_ptr, mask_idx = _lists_to_csr([list(x) for x in eval_data['mask_items']])
+            masks = [list(x) for x in eval_data['mask_items']]
+            if self.world_size > 1:                            # this rank scores the users it owns
+                keep = np.flatnonzero(self.shard.mine(users))
+                users, pos, masks = users[keep], [pos[k] for k in keep], [masks[k] for k in keep]
+            mask_ptr, mask_idx = _lists_to_csr(masks)
             pos_ptr, pos_idx = _lists_to_csr(pos)
             dev = self.device
             self._eval_cache[key] = (eval_data, pos, torch.from_numpy(users).to(dev),
@@ -154,17 +204,30 @@ class MFTrainer(BaseTrainer):
         # reference mf_trainer.py:134-161
         self.model.eval()
         actual, users, mask_ptr, mask_idx = self._eval_arrays(eval_data)
-        predicted = self.recommend(users, mask_ptr, mask_idx)
-        if self.cfg.get("host_metrics", False):
+        if self.world_size > 1:
+            p, r, m, n = self._evaluate_sharded(eval_data, users, mask_ptr, mask_idx)
+        elif self.cfg.get("host_metrics", False):
+            predicted = self.recommend(users, mask_ptr, mask_idx)
             # the checked definition (Python loops of reference metric.py); ~100x the kernel time
             p, r, m, n = ranking_metrics(actual, predicted.cpu().numpy().tolist(), self.cfg.top_n)
         else:
+            predicted = self.recommend(users, mask_ptr, mask_idx)
             pos_ptr, pos_idx = self._eval_cache[id(eval_data)][5:7]
             p, r, m, n = engine.rank_metrics(predicted, pos_ptr, pos_idx)[:4].tolist()
         if mode == 'test':
             logger.info(f"[Trainer] Test > precision@{self.cfg.top_n} : {p:.4f} / Recall@{self.cfg.top_n}: {r:.4f} / "
                         f"MAP@{self.cfg.top_n}: {m:.4f} / NDCG@{self.cfg.top_n}: {n:.4f}")
         return (p, r, m, n)
+
+    def _evaluate_sharded(self, eval_data, users, mask_ptr, mask_idx):
+        """Metrics over ALL eval users from per-rank sums: [non-empty users, 4 sums, users]."""
+        sums = torch.zeros(6, dtype=torch.float64, device=self.device)
+        if users.numel():
+            pos_ptr, pos_idx = self._eval_cache[id(eval_data)][5:7]
+            sums = engine.rank_metrics(self.recommend(users, mask_ptr, mask_idx), pos_ptr, pos_idx)[4:10].clone()
+        _dist().all_reduce(sums)
+        cnt, ps, rs, ms, ns, total = sums.tolist()
+        return (ps / total, rs / cnt, ms / cnt, ns / cnt)
 
     def _generate_top_k_recommendation(self, pred, mask_items):
         """reference mf_trainer.py:163-178 for ONE user's score vector (kept for callers
