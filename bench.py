@@ -194,6 +194,14 @@ def main():
                                "kind": "port",
                                "sample": f"{csteps} steps of batch {cpu_b} (same tables/shape/stream), {csec:.1f} s, "
                                          "torch-CPU op sequence of mf_trainer.py:104-114 with dense Adam"}
+        if args.sweep:
+            # the CPU op sequence at the reference's default batch and two larger ones
+            cs = {}
+            for b in (32, 4096, 65536):
+                cb = [tuple(t[:b].cpu() for t in pool[k]) for k in range(min(2, n_pool))]
+                tps_b, st_b, sec_b = time_steps(num_users, num_items, DIM, cb, budget_s=3.0)
+                cs[str(b)] = {"triplets_per_s": round(tps_b, 1), "steps": st_b, "seconds": round(sec_b, 1)}
+            out["cpu_baseline"]["batch_sweep"] = cs
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:

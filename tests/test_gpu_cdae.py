@@ -41,6 +41,50 @@ def test_gemm_f32_all_layouts(device, tA, tB, M, N, K, split):
     np.testing.assert_allclose(acc.cpu().numpy(), acc0 + want, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("tA", [False, True])
+@pytest.mark.parametrize("tB", [False, True])
+@pytest.mark.parametrize("M,N,K,split", [(6144, 6144, 40, 1),       # 128 x 128 workgroup tiles
+                                         (8200, 2048, 72, 1),       # 64 x 128 (+ ragged last row tile)
+                                         (2048, 8201, 72, 1),       # 128 x 64 (+ ragged last column tile)
+                                         (300, 260, 136, 1),        # 64 x 64, K a multiple of neither 16 nor 32
+                                         (256, 128, 5000, 8),       # split-K, atomic epilogue
+                                         (129, 131, 36, 1)])        # unaligned leading dimensions: generic kernel
+def test_gemm_f32_tiled_variants(device, tA, tB, M, N, K, split):
+    """Every workgroup-tile variant of the double-buffered kernel (the host picks the tile from the
+    problem size) in all four layouts, against float64 NumPy; strided views exercise lda > K."""
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(M + 3 * N + 7 * K + 2 * tA + tB)
+    pad = 8                                                       # operands are views into wider buffers
+    Af = rs.standard_normal((K, M + pad) if tA else (M, K + pad)).astype(np.float32)
+    Bf = rs.standard_normal((N, K + pad) if tB else (K, N + pad)).astype(np.float32)
+    dAf, dBf = torch.from_numpy(Af).to(device), torch.from_numpy(Bf).to(device)
+    dA = dAf[:, :M] if tA else dAf[:, :K]
+    dB = dBf[:, :K] if tB else dBf[:, :N]
+    A, B = dA.cpu().numpy().astype(np.float64), dB.cpu().numpy().astype(np.float64)
+    want = (A.T if tA else A) @ (B.T if tB else B)
+    tol = dict(rtol=1e-4, atol=2e-5 * np.sqrt(K) * 4)
+    lib_gemm = lambda **kw: _gemm_views(engine, dA, dB, tA, tB, M, N, K, **kw)
+    got = lib_gemm(split_k=split)
+    np.testing.assert_allclose(got.cpu().numpy(), want, **tol)
+    if split == 1:
+        bias = rs.standard_normal(N).astype(np.float32)
+        got = lib_gemm(bias=torch.from_numpy(bias).to(device), act=engine.ACT_SIGMOID)
+        np.testing.assert_allclose(got.cpu().numpy(), 1 / (1 + np.exp(-(want + bias))), rtol=1e-4, atol=1e-5)
+
+
+def _gemm_views(engine, dA, dB, tA, tB, M, N, K, bias=None, act=0, split_k=1):
+    """engine.gemm_f32 insists on contiguous tensors; strided row-major views go through the C ABI
+    directly (the ABI takes leading dimensions)."""
+    from yelprecommendation_amd import _lib
+    lib = _lib.load()
+    out = (torch.zeros if split_k > 1 else torch.empty)((M, N), dtype=torch.float32, device=dA.device)
+    rc = lib.yr_gemm_f32(int(tA), int(tB), M, N, K, dA.data_ptr(), dA.stride(0), dB.data_ptr(), dB.stride(0),
+                         out.data_ptr(), out.stride(0), bias.data_ptr() if bias is not None else None, int(act), 0,
+                         int(split_k), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    return out
+
+
 def _cfg(g, tmp_path, **kw):
     from yelprecommendation_amd.utils import make_config
     c = make_config("CDAE", hidden_size=int(g["hidden_size"]), lr=float(g["lr"]), batch_size=int(g["batch_size"]),
