@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 13
+#define YR_ENGINE_VERSION 14
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -260,11 +260,16 @@ int yr_mf_scores_gemm(const float *U, const float *I, const int64_t *users, int6
  *   descending, item id ascending among equal scores.  k <= 16.
  * The mask lists must be sorted ASCENDING inside each row (the kernel walks them with a cursor as
  * it sweeps the catalogue).  mask_ptr may be NULL.  f32 MFMA scores as yr_mf_scores_gemm.
+ * workspace: yr_mf_eval_topk_workspace_bytes(nrows, num_items, k) bytes of device memory (may be 0);
+ *   it holds the per-slice partial lists when the catalogue is cut into slices to fill the chip.
+ *   With workspace NULL or too small the kernel runs unsliced (same result, slower).
  * ------------------------------------------------------------------------- */
+int64_t yr_mf_eval_topk_workspace_bytes(int64_t nrows, int64_t num_items, int k);
 int yr_mf_eval_topk(const float *U, const float *I, const int64_t *users, int64_t nrows, int D,
                     int64_t num_users, int64_t num_items,
                     const int64_t *mask_ptr, const int64_t *mask_idx, float mask_value,
-                    int k, int64_t *out, int32_t *err_flag, void *stream);
+                    int k, int64_t *out, void *workspace, int64_t workspace_bytes,
+                    int32_t *err_flag, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Masked row-wise top-k      (reference trainers/mf_trainer.py:163-178,

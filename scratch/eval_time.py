@@ -19,3 +19,13 @@ torch.cuda.synchronize(); t=time.time()
 for _ in range(5): o2=engine.mf_eval_topk(U,I,users,ptr,sidx,10)
 torch.cuda.synchronize(); print('fused kernel only', round((time.time()-t)/5*1e3,2),'ms  -> ', round(2*nu*ni*d/((time.time()-t)/5)/1e12,1),'TFLOP/s f32')
 a=engine.mf_recommend(U,I,users,ptr,idx,10,fused=False); print('agree rows', (a==o2).all(1).float().mean().item())
+def tk(name, f, n=5):
+    f(); torch.cuda.synchronize(); t=time.time()
+    for _ in range(n): f()
+    torch.cuda.synchronize(); print(name, round((time.time()-t)/n*1e3,3),'ms')
+tk('k=10 masks   ', lambda: engine.mf_eval_topk(U,I,users,ptr,sidx,10))
+tk('k=10 no masks', lambda: engine.mf_eval_topk(U,I,users,None,None,10))
+tk('k=4  masks   ', lambda: engine.mf_eval_topk(U,I,users,ptr,sidx,4))
+tk('k=16 masks   ', lambda: engine.mf_eval_topk(U,I,users,ptr,sidx,16))
+tk('k=10 unsliced', lambda: engine.mf_eval_topk(U,I,users,ptr,sidx,10,sliced=False))
+tk('scores gemm only (unfused, 4.8 GB out)', lambda: engine.mf_scores_gemm(U,I,users[:8192]), 3)

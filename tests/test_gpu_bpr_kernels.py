@@ -185,3 +185,60 @@ def test_fused_eval_topk_edge_cases(device, d):
         a = engine.mf_recommend(t(U), t(I), t(users), t(ptr), t(idx), k, fused=True).cpu().numpy()
         b = engine.mf_recommend(t(U), t(I), t(users), t(ptr), t(idx), k, fused=False).cpu().numpy()
         assert (a == b).all(axis=1).mean() >= 0.98, (k, (a == b).all(axis=1).mean())
+
+
+@pytest.mark.parametrize("ni,expect_slices", [(4100, 2), (16411, 8)])
+def test_fused_eval_catalogue_slices_equal_one_slice(device, ni, expect_slices):
+    """The fused kernel cuts the catalogue into slices (one workgroup per 128 users x slice, partial
+    top-k lists merged by a second kernel) when there are few user rows: the result must be
+    IDENTICAL to the one-slice form (same scores, same tie order), masks included — also when a
+    user's masked items straddle slice boundaries and when a slice holds fewer than k unmasked items."""
+    from yelprecommendation_amd import engine, _lib
+    rs = np.random.RandomState(ni)
+    nu, n, d = 300, 201, 64
+    U, I = _tables(rs, nu, ni, d)
+    users = rs.randint(0, nu, size=n).astype(np.int64)
+    per = -(-ni // expect_slices)
+    lists = []
+    for r in range(n):
+        if r % 6 == 0:
+            m = np.arange(per - 20, per + 20)                              # straddles the first boundary
+        elif r % 6 == 1:
+            m = np.setdiff1d(np.arange(per), rs.choice(per, 3, replace=False))   # slice 0 keeps 3 items
+        else:
+            m = np.sort(rs.choice(ni, size=rs.randint(0, 80), replace=False))
+        lists.append(m.astype(np.int64))
+    ptr = np.zeros(n + 1, np.int64); ptr[1:] = np.cumsum([len(l) for l in lists])
+    idx = np.concatenate(lists).astype(np.int64)
+    t = lambda a: torch.from_numpy(a).to(device)
+    lib = _lib.load()
+    for k in (1, 10, 16):
+        assert lib.yr_mf_eval_topk_workspace_bytes(n, ni, k) == n * expect_slices * k * 8
+        a = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, sliced=True).cpu().numpy()
+        b = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, sliced=False).cpu().numpy()
+        np.testing.assert_array_equal(a, b)
+        c = engine.mf_recommend(t(U), t(I), t(users), t(ptr), t(idx), k, fused=False).cpu().numpy()
+        assert (a == c).all(axis=1).mean() >= 0.98
+        for r in range(n):
+            assert not set(a[r].tolist()) & set(lists[r].tolist())
+
+
+def test_fused_eval_mask_value_paths_agree(device):
+    """-FLT_MAX (the reference's value) takes the lazy masking path of the fused kernel, any other
+    value rewrites the scores before selection; with a value below every real score both must give
+    the same lists, including rows where masked items have to fill the tail."""
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(5)
+    nu, ni, n, d = 64, 2100, 50, 32
+    U, I = _tables(rs, nu, ni, d)
+    users = rs.randint(0, nu, size=n).astype(np.int64)
+    lists = [np.sort(rs.choice(ni, size=(ni - 4 if r % 9 == 0 else rs.randint(0, 50)), replace=False)) for r in range(n)]
+    ptr = np.zeros(n + 1, np.int64); ptr[1:] = np.cumsum([len(l) for l in lists])
+    idx = np.concatenate(lists).astype(np.int64)
+    t = lambda a: torch.from_numpy(a).to(device)
+    a = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), 10).cpu().numpy()
+    b = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), 10, mask_value=-1.0e30).cpu().numpy()
+    # the 4 unmasked items lead; the masked tail is ordered by item id in both (equal scores)
+    np.testing.assert_array_equal(a, b)
+    for r in range(0, n, 9):
+        assert set(a[r, :4].tolist()) == set(range(ni)) - set(lists[r].tolist())

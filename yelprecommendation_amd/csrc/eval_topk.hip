@@ -6,19 +6,25 @@
 //   pred = model([user] * num_items, arange(num_items))            (trainers/mf_trainer.py:138-140)
 //   pred[mask_items] = -3.40282e+38; argpartition; argsort         (trainers/mf_trainer.py:163-178)
 //
-// Workgroup = 2 waves = 64 eval users (32 per wave, their rows held in registers as the MFMA A
-// operand for the whole kernel).  The catalogue is walked in chunks of 128 items staged in LDS
-// (pitch D+4) and shared by both waves; per 32x32 tile D/2 x v_mfma_f32_32x32x2_f32 (exact f32).
-// Epilogue per tile: each lane holds one item's score for 16 users.  A score is a candidate when it
-// beats the user's current k-th best (threshold kept in LDS, refreshed per tile); candidates are
-// rare after the first few chunks (about k ln(I/k) per user in all), and each is inserted by its
-// own lane into the user's sorted top-k list in LDS.  A user's list is only ever touched by the
-// wave that owns the user, and within one accumulator register the 32 lanes of a half-wave all
-// belong to the SAME user, so insertions are serialised per half-wave with ballot/ffs and the two
-// halves proceed in parallel.
-// Masks: each user's mask list (CSR, item ids ASCENDING) is walked by a cursor as the chunks advance;
-// the (rare) masked items of the current 32-item tile become a 32-bit row mask in LDS, consulted
-// only for tiles that contain one.
+// Workgroup = 4 waves = 128 eval users (32 per wave) x one SLICE of the catalogue (blockIdx.y).
+// The users are the B operand of v_mfma_f32_32x32x2_f32 (exact f32), held in registers for the
+// whole kernel; the items are the A operand, staged through LDS in chunks shared by the four waves
+// (pitch D+4, next chunk prefetched into registers under the MFMAs).  In the 32x32 accumulator
+// lane (i, h) then holds the scores of ITS OWN user i for 16 items of the tile (the other half-wave
+// holds the other 16), so selection needs no cross-lane traffic:
+//   * every lane keeps a private sorted top-KK list (score, item) in registers;
+//   * a score that reaches the lane's threshold (its KK-th best as of the last flush — stale, hence
+//     a superset) is appended to the lane's private LDS buffer: one compare and one predicated
+//     ds_write per accumulator register;
+//   * when some lane's buffer is half full, the whole wave flushes: slot j of all 64 buffers is
+//     inserted into the 64 private lists in lockstep (a branch-free bubble pass), so the insertion
+//     cost is shared by every lane that has a slot-j candidate instead of being paid per candidate;
+//   * at the end the two half-waves exchange their lists with shuffles and merge them.
+// Masks: each lane walks its user's mask list (CSR, item ids ASCENDING) with a private cursor and
+// turns the masked items of the current tile into a 32-bit word.
+// Slicing the catalogue (S slices -> S x as many workgroups, two resident per CU) is what fills the
+// chip at Yelp2018 size (one wave per 32 users alone is < 1 wave per SIMD); each slice keeps its own
+// top-k per user and a second small kernel merges the S sorted partial lists.
 // Order: score descending, item id ascending among equal scores (as csrc/topk.hip).
 #include "common.h"
 
@@ -27,17 +33,13 @@ namespace yr {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kEtUsersPerWave = 32;
-constexpr int kEtWaves = 2;
+constexpr int kEtWaves = 4;
 constexpr int kEtThreads = kEtWaves * kWave;
-constexpr int kEtUsers = kEtWaves * kEtUsersPerWave;   // 64 per workgroup
-constexpr int kEtStageVec = 16;                        // float4 registers per thread for the next chunk
+constexpr int kEtUsers = kEtWaves * kEtUsersPerWave;   // 128 per workgroup
+constexpr int kEtChunkItems = 64;                      // items per LDS stage (two 32-item tiles)
 constexpr int kEtMaxK = 16;
-
-template <int D>
-struct EtChunk {
-  // items per LDS stage: chosen so that a chunk is exactly kEtStageVec float4 per thread
-  static constexpr int ITEMS = kEtStageVec * kEtThreads / (D / 4);     // 128 at D = 64
-};
+constexpr int kEtFlushAt = 8;                          // flush when some lane holds more than this
+constexpr int kEtBufCap = kEtFlushAt + 8;              // checked after every 8 accumulator registers
 
 struct TopEntry {
   float s;
@@ -48,201 +50,243 @@ __device__ __forceinline__ bool et_better(float s, int32_t i, float s2, int32_t 
   return s > s2 || (s == s2 && i < i2);
 }
 
-// Insert this register's candidates into the top-k lists.  The 32 lanes of a half-wave hold scores
-// of 32 items for ONE user (list L, threshold *tau); the two halves work on their two users in
-// parallel.  Per round each half takes its lowest candidate lane, broadcasts (score, item), all
-// lanes read the list in parallel (lane e = entry e), the insertion position is a popcount over
-// "entry stays ahead of the candidate", and the shifted list is written back in parallel.
-__device__ __forceinline__ void et_insert_candidates(volatile TopEntry* L, volatile float* tau, float s, int item,
-                                                  bool cand, int k, int lane) {
-  const int e = lane & 31;
-  const unsigned long long half_mask = (lane >> 5) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
-  unsigned long long pending = __ballot(cand);
-  while (pending) {
-    const unsigned long long mine = pending & half_mask;
-    const int first = mine ? __ffsll((long long)mine) - 1 : -1;        // uniform inside the half
-    const int src = first >= 0 ? first : lane;
-    const float cs = __shfl(s, src, kWave);
-    const int ci = __shfl(item, src, kWave);
-    // entry e of the list (lanes e >= k see a sentinel that never stays ahead)
-    const float ls = e < k ? L[e].s : -INFINITY;
-    const int li = e < k ? L[e].i : 0x7fffffff;
-    const bool ahead = e < k && et_better(ls, li, cs, ci);
-    const int pos = __popcll(__ballot(ahead) & half_mask);             // entries that stay in front
-    const float prev_s = __shfl_up(ls, 1, kWave);                      // entry e-1 (same half for e >= 1)
-    const int prev_i = __shfl_up(li, 1, kWave);
-    if (first >= 0 && pos < k && e < k && e >= pos) {
-      const float ns = e == pos ? cs : prev_s;
-      const int ni = e == pos ? ci : prev_i;
-      L[e].s = ns;
-      L[e].i = ni;
-      if (e == k - 1) *tau = ns;                                       // the new k-th best
-    }
-    if (lane == first) cand = false;
-    if (cand && s < *tau) cand = false;                                // re-check against the raised threshold
-    pending = __ballot(cand);
+// insert (cs, ci) into the lane's sorted list where `live`; the displaced entries bubble down
+template <int KK>
+__device__ __forceinline__ void et_bubble(float (&Ls)[KK], int32_t (&Li)[KK], float cs, int32_t ci, bool live) {
+#pragma unroll
+  for (int e = 0; e < KK; ++e) {
+    const bool sw = live && et_better(cs, ci, Ls[e], Li[e]);
+    const float ts = Ls[e];
+    const int32_t ti = Li[e];
+    Ls[e] = sw ? cs : ts;
+    Li[e] = sw ? ci : ti;
+    cs = sw ? ts : cs;
+    ci = sw ? ti : ci;
   }
 }
 
-template <int D>
+template <int D, int KK>
 __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
     const float* __restrict__ U, const float* __restrict__ I, const int64_t* __restrict__ users, int64_t nrows,
     int64_t num_users, int num_items, const int64_t* __restrict__ mask_ptr, const int64_t* __restrict__ mask_idx,
-    float mask_value, int k, int64_t* __restrict__ out, int32_t* __restrict__ err_flag) {
+    float mask_value, int k, int64_t* __restrict__ out, TopEntry* __restrict__ partial, int items_per_slice,
+    int32_t* __restrict__ err_flag) {
   constexpr int HALF = D / 2;
   constexpr int PITCH = D + 4;
-  constexpr int kEtChunk = EtChunk<D>::ITEMS;
-  __shared__ __attribute__((aligned(16))) float s_items[kEtChunk * PITCH];
-  // lists and thresholds are read by lanes other than the one that wrote them (same wave, in
-  // program order): volatile keeps the compiler from caching them in registers
-  __shared__ volatile TopEntry s_list[kEtUsers][kEtMaxK];
-  __shared__ volatile float s_tau[kEtUsers];        // current k-th best score per user
-  __shared__ int64_t s_cur[kEtUsers];               // cursor into the user's mask list
-  __shared__ int64_t s_end[kEtUsers];
-  __shared__ uint32_t s_mbits[kEtUsers];            // masked items of the current 32-item tile
+  constexpr int NV = kEtChunkItems * (D / 4) / kEtThreads;       // float4 per thread per chunk (>= 1)
+  static_assert(NV >= 1, "chunk too small for this D");
+  __shared__ __attribute__((aligned(16))) float s_items[2][kEtChunkItems * PITCH];   // double-buffered
+  __shared__ TopEntry s_buf[kEtBufCap][kEtThreads];               // slot-major: conflict-free per slot
 
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int i = lane & 31, h = lane >> 5;
-  const int64_t row0 = (int64_t)blockIdx.x * kEtUsers;
-  const int ubase = wave * kEtUsersPerWave;          // this wave's users inside the workgroup
+  const int64_t row = (int64_t)blockIdx.x * kEtUsers + wave * kEtUsersPerWave + i;   // this lane's user row
+  const int item_lo = blockIdx.y * items_per_slice;  // this workgroup's slice of the catalogue
+  const int item_hi = min(num_items, item_lo + items_per_slice);
 
-  // per-user state
-  for (int q = threadIdx.x; q < kEtUsers; q += kEtThreads) {
-    const int64_t r = row0 + q;
-    s_tau[q] = r < nrows ? -INFINITY : INFINITY;     // rows beyond the input never become candidates
-    s_cur[q] = (mask_ptr && r < nrows) ? mask_ptr[r] : 0;
-    s_end[q] = (mask_ptr && r < nrows) ? mask_ptr[r + 1] : 0;
-    for (int e = 0; e < kEtMaxK; ++e) { s_list[q][e].s = -INFINITY; s_list[q][e].i = 0x7fffffff; }
-  }
-
-  // A operand: this lane's half of its user's row
-  float a[HALF];
+  // B operand: this lane's half of its user's row (zeros for rows beyond the input / bad ids)
+  float ub[HALF];
+  bool ok = row < nrows;
   {
-    const int64_t r = row0 + ubase + i;
-    int64_t uid = r < nrows ? users[r] : 0;
-    bool ok = r < nrows;
+    int64_t uid = ok ? users[row] : 0;
     if (ok && (uint64_t)uid >= (uint64_t)num_users) {
       if (err_flag) atomicOr(err_flag, YR_FLAG_BAD_USER);
       ok = false;
-      uid = 0;
     }
 #pragma unroll
     for (int q = 0; q < HALF / 4; ++q) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok) v = *reinterpret_cast<const float4*>(U + uid * D + h * HALF + 4 * q);
-      a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+      ub[4 * q + 0] = v.x; ub[4 * q + 1] = v.y; ub[4 * q + 2] = v.z; ub[4 * q + 3] = v.w;
     }
   }
 
-  __syncthreads();
-  // lane i < 32 owns user (ubase + i)'s mask cursor; its next masked item id stays in a register so
-  // that the list is only touched when a masked item actually falls into the current tile
+  // private list, threshold, buffer fill and mask cursor
+  float Ls[KK];
+  int32_t Li[KK];
+#pragma unroll
+  for (int e = 0; e < KK; ++e) { Ls[e] = ok ? -INFINITY : INFINITY; Li[e] = 0x7fffffff; }   // +inf: nothing ever enters
+  float tau = Ls[KK - 1];
+  int cnt = 0;
+  const bool lazy_mask = mask_value <= -3.0e38f;     // uniform
+  // the next TWO masked item ids stay in registers: the load that refills the second one is issued
+  // a tile (or more) before its value is needed, so the sweep never waits on it
   int64_t m_cur = 0, m_end = 0;
-  int next_masked = 0x7fffffff;
-  if (mask_ptr && h == 0) {
-    m_cur = s_cur[ubase + i];
-    m_end = s_end[ubase + i];
+  int next_masked = 0x7fffffff, after_next = 0x7fffffff;
+  if (mask_ptr && row < nrows) {
+    m_cur = mask_ptr[row];
+    m_end = mask_ptr[row + 1];
+    while (m_cur < m_end && mask_idx[m_cur] < item_lo) ++m_cur;   // masks below this slice
     if (m_cur < m_end) next_masked = (int)mask_idx[m_cur];
+    if (m_cur + 1 < m_end) after_next = (int)mask_idx[m_cur + 1];
   }
+
+  auto flush = [&]() {
+    for (int j = 0; __ballot(j < cnt) != 0ull; ++j) {              // wave-uniform trip count
+      const bool live = j < cnt;
+      const float cs = s_buf[j][threadIdx.x].s;
+      const int32_t ci = s_buf[j][threadIdx.x].i;
+      et_bubble<KK>(Ls, Li, cs, ci, live);
+    }
+    cnt = 0;
+    tau = Ls[KK - 1];
+  };
 
   // register staging of the item chunks: the loads of chunk c+1 are issued before the tiles of
   // chunk c are computed and land in LDS after the next barrier (global latency hidden under MFMA)
-  float4 stage[kEtStageVec];
+  float4 stage[NV];
   auto fetch = [&](int c0) {
 #pragma unroll
-    for (int v = 0; v < kEtStageVec; ++v) {
+    for (int v = 0; v < NV; ++v) {
       const int q = threadIdx.x + v * kEtThreads;
       const int r = q / (D / 4), c = q % (D / 4);
       stage[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c0 + r < num_items) stage[v] = *reinterpret_cast<const float4*>(I + (int64_t)(c0 + r) * D + 4 * c);
+      if (c0 + r < item_hi) stage[v] = *reinterpret_cast<const float4*>(I + (int64_t)(c0 + r) * D + 4 * c);
     }
   };
-  fetch(0);
-  for (int c0 = 0; c0 < num_items; c0 += kEtChunk) {
-    __syncthreads();                                 // previous chunk fully consumed
+  auto stash = [&](float* dst) {
 #pragma unroll
-    for (int v = 0; v < kEtStageVec; ++v) {
+    for (int v = 0; v < NV; ++v) {
       const int q = threadIdx.x + v * kEtThreads;
-      *reinterpret_cast<float4*>(s_items + (q / (D / 4)) * PITCH + 4 * (q % (D / 4))) = stage[v];
+      *reinterpret_cast<float4*>(dst + (q / (D / 4)) * PITCH + 4 * (q % (D / 4))) = stage[v];
     }
-    __syncthreads();
-    if (c0 + kEtChunk < num_items) fetch(c0 + kEtChunk);
+  };
+  fetch(item_lo);
+  stash(s_items[0]);
+  __syncthreads();
+  int cur = 0;
+  for (int c0 = item_lo; c0 < item_hi; c0 += kEtChunkItems) {
+    const bool more = c0 + kEtChunkItems < item_hi;
+    if (more) fetch(c0 + kEtChunkItems);             // lands in the other buffer at the end of this chunk
+    const float* chunk = s_items[cur];
 
 #pragma unroll 1
-    for (int t = 0; t < kEtChunk / 32; ++t) {
+    for (int t = 0; t < kEtChunkItems / 32; ++t) {
       const int item0 = c0 + t * 32;
-      if (item0 >= num_items) break;                 // wave-uniform
-      // ---- scores of 32 users x 32 items
+      if (item0 >= item_hi) break;                   // wave-uniform
+      // ---- scores: acc[reg] = <item item0 + row(reg, h), user of this lane>
       f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       {
-        const float* src = s_items + (t * 32 + i) * PITCH + h * HALF;
+        const float* src = chunk + (t * 32 + i) * PITCH + h * HALF;
 #pragma unroll
         for (int q = 0; q < HALF / 4; ++q) {
           const float4 b = *reinterpret_cast<const float4*>(src + 4 * q);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 0], b.x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 1], b.y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 2], b.z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 3], b.w, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, ub[4 * q + 0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, ub[4 * q + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, ub[4 * q + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, ub[4 * q + 3], acc, 0, 0, 0);
         }
       }
-      // ---- masked items of this tile: lane i (< 32) advances user (ubase + i)'s cursor
-      bool any_masked = false;
-      if (mask_ptr) {
-        uint32_t bits = 0;
-        while (next_masked < item0 + 32) {           // only lanes h == 0 can have next_masked < INT_MAX
-          if (next_masked >= item0) bits |= 1u << (next_masked - item0);
-          ++m_cur;
-          next_masked = m_cur < m_end ? (int)mask_idx[m_cur] : 0x7fffffff;
+      // ---- masked items of this tile (bit r = item item0 + r), shifted to this half's rows
+      uint32_t bits = 0;
+      while (next_masked < item0 + 32) {
+        if (next_masked >= item0) bits |= 1u << (next_masked - item0);
+        ++m_cur;
+        next_masked = after_next;
+        after_next = m_cur + 1 < m_end ? (int)mask_idx[m_cur + 1] : 0x7fffffff;
+      }
+      // With the reference's mask value (-FLT_MAX, below every real score) the mask is applied
+      // lazily, inside the candidate branch only: a masked item whose real score does not beat the
+      // threshold could not enter with -FLT_MAX either (the threshold is -inf, and then every
+      // score is a candidate, or already >= -FLT_MAX).  Any other mask value rewrites the scores first.
+      const uint32_t mine = bits >> (4 * h);
+      if (!lazy_mask && __ballot(bits != 0) != 0ull) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          if ((mine >> ((reg & 3) + 8 * (reg >> 2))) & 1u) acc[reg] = mask_value;
+      }
+      if (item0 + 32 > item_hi) {                    // wave-uniform: last, partial tile of the slice
+        const uint32_t beyond = (~0u << (item_hi - item0)) >> (4 * h);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          if ((beyond >> ((reg & 3) + 8 * (reg >> 2))) & 1u) acc[reg] = -INFINITY;   // not an item
+      }
+      // ---- candidates -> private buffer.  Strict comparison is exact: a lane meets its items in
+      // ascending id order, so a later score EQUAL to the threshold loses the tie anyway; it also
+      // keeps the -inf of the rows beyond the slice out.
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int reg = half * 8 + q;
+          float sc = acc[reg];
+          if (sc > tau) {
+            if (lazy_mask && ((mine >> ((reg & 3) + 8 * (reg >> 2))) & 1u)) sc = mask_value;
+            if (sc > tau) {
+              TopEntry c;
+              c.s = sc;
+              c.i = item0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+              s_buf[cnt][threadIdx.x] = c;
+              ++cnt;
+            }
+          }
         }
-        any_masked = __ballot(bits != 0) != 0ull;    // wave-uniform
-        if (any_masked && h == 0) s_mbits[ubase + i] = bits;   // read back by the whole wave below
+        if (__ballot(cnt > kEtFlushAt) != 0ull) flush();
       }
-      const int item = item0 + i;
-      const bool item_ok = item < num_items;
-      // ---- candidates: one bit per accumulator register, tested against register copies of the
-      // thresholds (refreshed from LDS only after this wave inserted something)
-      if (any_masked) {
+    }
+    // one barrier per chunk: everyone is done reading s_items[cur ^ 1] since the previous barrier,
+    // so the next chunk can be written there while slower waves still read s_items[cur]
+    if (more) stash(s_items[cur ^ 1]);
+    __syncthreads();
+    cur ^= 1;
+  }
+  flush();
+
+  // ---- merge the two half-waves' lists of the same user (lane i <-> lane i + 32)
+  {
+    float Os[KK];
+    int32_t Oi[KK];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int ul = ubase + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-          if ((s_mbits[ul] >> i) & 1u) acc[reg] = mask_value;
+    for (int e = 0; e < KK; ++e) {
+      Os[e] = __shfl_xor(Ls[e], 32, kWave);
+      Oi[e] = __shfl_xor(Li[e], 32, kWave);
+    }
+#pragma unroll
+    for (int e = 0; e < KK; ++e) et_bubble<KK>(Ls, Li, Os[e], Oi[e], Oi[e] != 0x7fffffff);
+  }
+  if (h == 0 && row < nrows) {
+#pragma unroll
+    for (int e = 0; e < KK; ++e) {
+      if (e < k) {
+        if (partial) {
+          TopEntry t;
+          t.s = Ls[e];
+          t.i = Li[e];
+          partial[(row * gridDim.y + blockIdx.y) * k + e] = t;
+        } else {
+          out[row * k + e] = Li[e] == 0x7fffffff ? -1 : (int64_t)Li[e];
         }
-      }
-      uint32_t cmask = 0;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        // a stale (lower) threshold is safe: it only lets extra candidates through to the exact check
-        const float tau = const_cast<const float*>(s_tau)[ubase + (reg & 3) + 8 * (reg >> 2) + 4 * h];
-        if (acc[reg] >= tau) cmask |= 1u << reg;
-      }
-      if (!item_ok) cmask = 0;
-      if (__ballot(cmask != 0) == 0ull) continue;    // no candidate in this tile
-      // registers that hold a candidate in some lane (wave-uniform 16-bit mask), then ONE copy of the
-      // insertion code looped over them (the accumulator is picked with a select chain: no dynamic
-      // register indexing, no 16-fold code expansion)
-      uint32_t regs = 0;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg)
-        if (__ballot((cmask >> reg) & 1u) != 0ull) regs |= 1u << reg;
-      while (regs) {
-        const int r = __builtin_ctz(regs);           // wave-uniform
-        regs &= regs - 1;
-        float sc = acc[0];
-#pragma unroll
-        for (int q = 1; q < 16; ++q) sc = r == q ? acc[q] : sc;
-        const int ul = ubase + (r & 3) + 8 * (r >> 2) + 4 * h;
-        et_insert_candidates(s_list[ul], &s_tau[ul], sc, item, ((cmask >> r) & 1u) != 0, k, lane);
       }
     }
   }
-  __syncthreads();
-  for (int q = threadIdx.x; q < kEtUsers * k; q += kEtThreads) {
-    const int ul = q / k, e = q % k;
-    const int64_t r = row0 + ul;
-    if (r < nrows) {
-      const int32_t it = s_list[ul][e].i;
-      out[r * k + e] = it == 0x7fffffff ? -1 : (int64_t)it;
+}
+
+// out[r, :] = the k best of the S sorted partial lists of row r (score descending, item ascending
+// among equal scores; empty slots carry item 0x7fffffff and lose every comparison).  One thread per
+// row: S cursors, k rounds.
+constexpr int kEtMaxSlices = 8;
+
+__global__ __launch_bounds__(kBlock) void mf_eval_merge_kernel(const TopEntry* __restrict__ partial, int64_t nrows,
+                                                               int S, int k, int64_t* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= nrows) return;
+  const TopEntry* P = partial + r * S * k;
+  int cur[kEtMaxSlices] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int e = 0; e < k; ++e) {
+    int best = -1;
+    float bs = 0.0f;
+    int32_t bi = 0x7fffffff;
+    for (int s = 0; s < S; ++s) {
+      if (cur[s] >= k) continue;
+      const TopEntry t = P[s * k + cur[s]];
+      if (t.i == 0x7fffffff) continue;
+      if (best < 0 || et_better(t.s, t.i, bs, bi)) { best = s; bs = t.s; bi = t.i; }
     }
+    if (best >= 0) {
+#pragma unroll
+      for (int s = 0; s < kEtMaxSlices; ++s) cur[s] += (s == best);
+    }
+    out[r * k + e] = best >= 0 ? (int64_t)bi : -1;
   }
 }
 
@@ -250,21 +294,46 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
 
 using namespace yr;
 
+// slices of the catalogue per 128-user workgroup row: two workgroups per CU in one round
+static int et_slices(int64_t nrows, int64_t num_items) {
+  const int64_t rows = (nrows + kEtUsers - 1) / kEtUsers;
+  int64_t S = 512 / rows;
+  const int64_t by_items = num_items / 2048;          // keep slices long enough to amortise their top-k
+  if (S > by_items) S = by_items;
+  if (S > kEtMaxSlices) S = kEtMaxSlices;
+  return (int)(S < 1 ? 1 : S);
+}
+
+extern "C" int64_t yr_mf_eval_topk_workspace_bytes(int64_t nrows, int64_t num_items, int k) {
+  if (nrows < 0 || num_items <= 0 || k <= 0 || k > kEtMaxK) return YR_ERR_BADARG;
+  const int S = et_slices(nrows, num_items);
+  return S > 1 ? nrows * S * k * (int64_t)sizeof(TopEntry) : 0;
+}
 
 extern "C" int yr_mf_eval_topk(const float* U, const float* I, const int64_t* users, int64_t nrows, int D,
                                int64_t num_users, int64_t num_items, const int64_t* mask_ptr,
-                               const int64_t* mask_idx, float mask_value, int k, int64_t* out, int32_t* err_flag,
-                               void* stream) {
+                               const int64_t* mask_idx, float mask_value, int k, int64_t* out, void* workspace,
+                               int64_t workspace_bytes, int32_t* err_flag, void* stream) {
   if (nrows < 0 || num_users <= 0 || num_items <= 0 || num_items > 0x7ffffff0 || k <= 0 || k > kEtMaxK)
     return YR_ERR_BADARG;
   if (nrows == 0) return 0;
   if (!U || !I || !users || !out || (mask_ptr && !mask_idx)) return YR_ERR_BADARG;
-  const unsigned grid = (unsigned)((nrows + kEtUsers - 1) / kEtUsers);
+  int S = et_slices(nrows, num_items);
+  if (S > 1 && (!workspace || workspace_bytes < nrows * S * k * (int64_t)sizeof(TopEntry))) S = 1;   // no room: one slice
+  int per = (int)((num_items + S - 1) / S);
+  per = (per + 31) / 32 * 32;                          // whole 32-item tiles
+  S = (int)((num_items + per - 1) / per);
+  TopEntry* partial = S > 1 ? static_cast<TopEntry*>(workspace) : nullptr;
+  const dim3 grid((unsigned)((nrows + kEtUsers - 1) / kEtUsers), (unsigned)S);
   hipStream_t s = (hipStream_t)stream;
-#define YR_ET_CASE(DD)                                                                                          \
-  case DD:                                                                                                      \
-    hipLaunchKernelGGL((mf_eval_topk_kernel<DD>), dim3(grid), dim3(kEtThreads), 0, s, U, I, users, nrows,       \
-                       num_users, (int)num_items, mask_ptr, mask_idx, mask_value, k, out, err_flag);            \
+#define YR_ET_LAUNCH(DD, KK)                                                                                    \
+  hipLaunchKernelGGL((mf_eval_topk_kernel<DD, KK>), grid, dim3(kEtThreads), 0, s, U, I, users, nrows,           \
+                     num_users, (int)num_items, mask_ptr, mask_idx, mask_value, k, out, partial, per, err_flag)
+#define YR_ET_CASE(DD)                                     \
+  case DD:                                                 \
+    if (k <= 4) YR_ET_LAUNCH(DD, 4);                       \
+    else if (k <= 10) YR_ET_LAUNCH(DD, 10);                \
+    else YR_ET_LAUNCH(DD, 16);                             \
     break
   switch (D) {
     YR_ET_CASE(16);
@@ -274,5 +343,9 @@ extern "C" int yr_mf_eval_topk(const float* U, const float* I, const int64_t* us
     default: return YR_ERR_UNSUPPORTED;
   }
 #undef YR_ET_CASE
+#undef YR_ET_LAUNCH
+  if (S > 1)
+    hipLaunchKernelGGL(mf_eval_merge_kernel, dim3((unsigned)((nrows + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
+                       partial, nrows, S, k, out);
   return launch_status();
 }

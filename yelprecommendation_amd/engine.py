@@ -401,19 +401,25 @@ def sort_mask_rows(mask_ptr, mask_idx):
     return mask_idx[order].contiguous()
 
 
-def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALUE, out=None):
+def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALUE, out=None, sliced=True):
     """Fused full-catalogue scoring + mask + top-k (no score matrix).  ``mask_idx_sorted``: CSR mask
-    lists with ascending ids inside each row (see :func:`sort_mask_rows`)."""
+    lists with ascending ids inside each row (see :func:`sort_mask_rows`).  ``sliced=False`` withholds
+    the workspace, i.e. forces the one-slice form of the kernel (tests)."""
     lib = _lib.load()
     nu, ni, d = _table_dims(U, I)
     n = users.numel()
     if out is None:
         out = torch.empty((n, k), dtype=torch.int64, device=U.device)
     flag = new_error_flag(U.device)
+    ws_bytes = lib.yr_mf_eval_topk_workspace_bytes(n, ni, int(k)) if sliced else 0
+    if ws_bytes < 0:
+        check(int(ws_bytes), "yr_mf_eval_topk_workspace_bytes")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=U.device) if ws_bytes else None
     check(lib.yr_mf_eval_topk(_dev(U, torch.float32, "U"), _dev(I, torch.float32, "I"),
                               _dev(users, torch.int64, "users"), n, d, nu, ni,
                               _opt(mask_ptr, torch.int64, "mask_ptr"), _opt(mask_idx_sorted, torch.int64, "mask_idx"),
-                              float(mask_value), int(k), _dev(out, torch.int64, "out"), flag.data_ptr(), _stream()),
+                              float(mask_value), int(k), _dev(out, torch.int64, "out"),
+                              ws.data_ptr() if ws is not None else None, ws_bytes, flag.data_ptr(), _stream()),
           "yr_mf_eval_topk")
     raise_on_flag(flag, "mf_eval_topk")
     return out
