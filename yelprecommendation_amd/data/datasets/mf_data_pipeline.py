@@ -66,7 +66,16 @@ class MFDataPipeline(DataPipeline):
         train_df, valid_df, test_df = frames
 
         def pos_lists(frame):
-            return frame.groupby('user_id').agg({'business_id': [('pos_items', list)]}).droplevel(0, 1)
+            # = frame.groupby('user_id').agg({'business_id': [('pos_items', list)]}).droplevel(0, 1)
+            # (reference mf_data_pipeline.py:38-41) without pandas' per-group Python loop: users
+            # ascending, row order kept inside each user's list, plain Python ints
+            u, b = frame['user_id'].values, frame['business_id'].values
+            by_user = np.argsort(u, kind='stable')
+            us, bs = u[by_user], b[by_user]
+            cut = np.flatnonzero(np.r_[True, us[1:] != us[:-1], True])
+            lists = pd.Series([bs[i:j].tolist() for i, j in zip(cut[:-1], cut[1:])], dtype=object,
+                              index=pd.Index(us[cut[:-1]], name='user_id'))
+            return pd.DataFrame({'pos_items': lists})
 
         train_pos_df = pos_lists(train_df)
         valid_pos_df = pos_lists(valid_df)
