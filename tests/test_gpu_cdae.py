@@ -173,7 +173,12 @@ def test_trainer_run_matches_reference(g, tmp_path, device):
                  "input_mask": torch.from_numpy(g["test_input"][i:i + 32].astype(np.float32)),
                  "test_mask": torch.from_numpy(g["test_mask"][i:i + 32].astype(np.float32))}
                 for i in range(0, len(users), 32)]
-    np.testing.assert_allclose(t.evaluate(tbatches), g["test_metrics"], atol=1e-3, rtol=0)
+    dev_metrics = t.evaluate(tbatches)
+    np.testing.assert_allclose(dev_metrics, g["test_metrics"], atol=1e-3, rtol=0)
+    # the device-side metric sums against the reference's host route (np.nonzero + metric.py loops)
+    t.cfg.host_metrics = True
+    np.testing.assert_allclose(t.evaluate(tbatches), dev_metrics, rtol=1e-12)
+    np.testing.assert_allclose(t.validate(vbatches)[1:], out[1:], rtol=1e-12)
 
 
 def test_config5_shape_step_matches_oracle(device, tmp_path):

@@ -5,7 +5,10 @@ Same constructor ``CDAETrainer(cfg, num_items, num_users)`` and the same contrac
 ``(loss, precision, recall, map, ndcg)``, ``evaluate`` returns the four metrics.  Seen items are
 masked the reference's way — scores multiplied by ``logical_not(input_mask)`` (-> 0, valid
 because sigmoid > 0; trainers/cdae_trainer.py:132) — through the masked top-k kernel with
-mask value 0.
+mask value 0.  The four metrics are computed on the device per batch (``yr_rank_metrics`` sums,
+one read-back per validate / evaluate) instead of copying every [B, I] mask to the host for
+``np.nonzero`` and the Python loops of metric.py; ``cfg.host_metrics=True`` selects the reference's
+host route (``_generate_target_and_top_k_recommendation`` + ``metric.ranking_metrics``).
 """
 import numpy as np
 import torch
@@ -65,6 +68,8 @@ class CDAETrainer(BaseTrainer):
         self.model.eval()
         self._loss_accum.zero_()
         actual, predicted = [], []
+        host = self.cfg.get("host_metrics", False)
+        sums = torch.zeros(6, dtype=torch.float64, device=self.device)
         with torch.no_grad():
             for data in valid_dataloader:
                 user_id, input_mask = data['user_id'].to(self.device), data['input_mask'].to(self.device)
@@ -77,11 +82,13 @@ class CDAETrainer(BaseTrainer):
                 else:
                     loss = self.loss(pred, target)
                 self._accumulate(loss)
-                batch_actual, batch_predicted = self._generate_target_and_top_k_recommendation(pred, valid_mask, input_mask)
-                actual.extend(batch_actual)
-                predicted.extend(batch_predicted)
-        predicted = np.concatenate(predicted, axis=0)
-        p, r, m, n = ranking_metrics(actual, predicted.tolist(), self.cfg.top_n)
+                if host:
+                    batch_actual, batch_predicted = self._generate_target_and_top_k_recommendation(pred, valid_mask, input_mask)
+                    actual.extend(batch_actual)
+                    predicted.extend(batch_predicted)
+                else:
+                    sums += self._metric_sums(pred, valid_mask, input_mask)
+        p, r, m, n = self._metrics(host, actual, predicted, sums)
         return (float(self._loss_accum.item()), p, r, m, n)
 
     @log_metric
@@ -89,19 +96,45 @@ class CDAETrainer(BaseTrainer):
         # reference cdae_trainer.py:90-121
         self.model.eval()
         actual, predicted = [], []
+        host = self.cfg.get("host_metrics", False)
+        sums = torch.zeros(6, dtype=torch.float64, device=self.device)
         with torch.no_grad():
             for data in test_dataloader:
                 input_mask, user_id, test_mask = data['input_mask'].to(self.device), \
                     data['user_id'].to(self.device), data['test_mask'].to(self.device)
                 pred = self.model(user_id, input_mask)
-                batch_actual, batch_predicted = self._generate_target_and_top_k_recommendation(pred, test_mask, input_mask)
-                actual.extend(batch_actual)
-                predicted.extend(batch_predicted)
-        predicted = np.concatenate(predicted, axis=0)
-        p, r, m, n = ranking_metrics(actual, predicted.tolist(), self.cfg.top_n)
+                if host:
+                    batch_actual, batch_predicted = self._generate_target_and_top_k_recommendation(pred, test_mask, input_mask)
+                    actual.extend(batch_actual)
+                    predicted.extend(batch_predicted)
+                else:
+                    sums += self._metric_sums(pred, test_mask, input_mask)
+        p, r, m, n = self._metrics(host, actual, predicted, sums)
         logger.info(f"[Trainer] Test > precision@{self.cfg.top_n} : {p:.4f} / Recall@{self.cfg.top_n}: {r:.4f} / "
                     f"MAP@{self.cfg.top_n}: {m:.4f} / NDCG@{self.cfg.top_n}: {n:.4f}")
         return (p, r, m, n)
+
+    def _metrics(self, host, actual, predicted, sums):
+        if host:
+            return ranking_metrics(actual, np.concatenate(predicted, axis=0).tolist(), self.cfg.top_n)
+        cnt, ps, rs, ms, ns, total = sums.tolist()                 # the one read-back
+        return (ps / total, rs / cnt, ms / cnt, ns / cnt)
+
+    @staticmethod
+    def _rows_to_csr(mask):
+        """Non-zero column ids of every row of a [B, I] mask as CSR (ascending inside a row, the
+        order np.nonzero gives the reference at cdae_trainer.py:125)."""
+        nz = mask.nonzero()
+        ptr = torch.zeros(mask.shape[0] + 1, dtype=torch.int64, device=mask.device)
+        ptr[1:] = torch.cumsum(torch.bincount(nz[:, 0], minlength=mask.shape[0]), 0)
+        return ptr, nz[:, 1].contiguous()
+
+    def _metric_sums(self, pred, actual_mask, pred_mask):
+        """[users with held-out items, precision / recall / AP / NDCG sums, users] of one batch."""
+        mask_ptr, mask_idx = self._rows_to_csr(pred_mask)
+        top = engine.topk_masked(pred.detach().contiguous(), mask_ptr, mask_idx, self.cfg.top_n, mask_value=0.0)
+        pos_ptr, pos_idx = self._rows_to_csr(actual_mask)
+        return engine.rank_metrics(top, pos_ptr, pos_idx)[4:10]
 
     def _generate_target_and_top_k_recommendation(self, pred, actual_mask, pred_mask):
         # reference cdae_trainer.py:123-144
