@@ -9,7 +9,8 @@
 //   AP         sum over hit positions i of |set(actual[:i]) & set(pred[:i])| / i, divided by
 //              len(actual) — the ACTUAL list is truncated to i as well
 //   NDCG       DCG over positions 1..min(len(actual), k) only; ideal DCG = same positions, all hits
-// One thread per user (lists are tens of items); float64 sums, fixed-order two-level reduction.
+// One thread per user (lists are tens of items); float64 sums, fixed-order reduction (wave butterfly
+// per workgroup, then one wave over the workgroup partials).
 #include "common.h"
 
 namespace yr {
@@ -22,13 +23,14 @@ __device__ __forceinline__ bool contains(const int64_t* a, int n, int64_t x) {
 
 // partial[b * 5 + {0..4}] = sums over the block of precision, recall, AP, NDCG terms and the number
 // of users with a non-empty actual list
-__global__ __launch_bounds__(kBlock) void rank_metrics_kernel(const int64_t* __restrict__ topk, int64_t n, int k,
+constexpr int kMetricBlock = kWave;   // one wave per workgroup: ~500 workgroups at Yelp2018 size, every CU busy
+
+__global__ __launch_bounds__(kMetricBlock) void rank_metrics_kernel(const int64_t* __restrict__ topk, int64_t n, int k,
                                                               const int64_t* __restrict__ pos_ptr,
                                                               const int64_t* __restrict__ pos_idx,
                                                               double* __restrict__ partial) {
-  __shared__ double s_red[5][kWavesPerBlock];
   double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t u = (int64_t)blockIdx.x * kMetricBlock + threadIdx.x;
   if (u < n) {
     const int64_t* pred = topk + u * k;
     const int64_t* act = pos_idx + pos_ptr[u];
@@ -71,31 +73,29 @@ __global__ __launch_bounds__(kBlock) void rank_metrics_kernel(const int64_t* __r
       v[4] = 1.0;
     }
   }
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 #pragma unroll
   for (int q = 0; q < 5; ++q) {
     double x = v[q];
 #pragma unroll
     for (int m = kWave / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, kWave);
-    if (lane == 0) s_red[q][wave] = x;
-  }
-  __syncthreads();
-  if (threadIdx.x < 5) {
-    double t = 0.0;
-#pragma unroll
-    for (int w = 0; w < kWavesPerBlock; ++w) t += s_red[threadIdx.x][w];
-    partial[(int64_t)blockIdx.x * 5 + threadIdx.x] = t;
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * 5 + q] = x;
   }
 }
 
 // out[0..3] = precision, recall, MAP, NDCG;  out[4] = users with a non-empty actual list;
 // out[5..8] = the four un-normalised sums, out[9] = n (what a user-sharded evaluation all-reduces)
-__global__ void rank_metrics_finalize_kernel(const double* __restrict__ partial, int nblocks, int64_t n,
-                                             double* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(kWave) void rank_metrics_finalize_kernel(const double* __restrict__ partial, int nblocks,
+                                                                      int64_t n, double* __restrict__ out) {
+  // lane l sums blocks l, l + 64, ... in order, then a fixed butterfly: deterministic
   double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int b = 0; b < nblocks; ++b)
+  for (int b = threadIdx.x; b < nblocks; b += kWave)
+#pragma unroll
     for (int q = 0; q < 5; ++q) s[q] += partial[(int64_t)b * 5 + q];
+#pragma unroll
+  for (int q = 0; q < 5; ++q)
+#pragma unroll
+    for (int m = kWave / 2; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m, kWave);
+  if (threadIdx.x != 0) return;
   out[0] = s[0] / (double)n;
   out[1] = s[1] / s[4];
   out[2] = s[2] / s[4];
@@ -111,16 +111,17 @@ using namespace yr;
 
 extern "C" int64_t yr_rank_metrics_workspace_bytes(int64_t n) {
   if (n < 0) return YR_ERR_BADARG;
-  return (int64_t)((n + kBlock - 1) / kBlock + 1) * 5 * (int64_t)sizeof(double);
+  return (int64_t)((n + kMetricBlock - 1) / kMetricBlock + 1) * 5 * (int64_t)sizeof(double);
 }
 
 extern "C" int yr_rank_metrics(const int64_t* topk, int64_t n, int k, const int64_t* pos_ptr, const int64_t* pos_idx,
                                double* workspace, double* out, void* stream) {
   if (n <= 0 || k <= 0) return YR_ERR_BADARG;
   if (!topk || !pos_ptr || !workspace || !out) return YR_ERR_BADARG;
-  const int nblocks = (int)((n + kBlock - 1) / kBlock);
+  const int nblocks = (int)((n + kMetricBlock - 1) / kMetricBlock);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(rank_metrics_kernel, dim3(nblocks), dim3(kBlock), 0, s, topk, n, k, pos_ptr, pos_idx, workspace);
-  hipLaunchKernelGGL(rank_metrics_finalize_kernel, dim3(1), dim3(64), 0, s, workspace, nblocks, n, out);
+  hipLaunchKernelGGL(rank_metrics_kernel, dim3(nblocks), dim3(kMetricBlock), 0, s, topk, n, k, pos_ptr, pos_idx,
+                     workspace);
+  hipLaunchKernelGGL(rank_metrics_finalize_kernel, dim3(1), dim3(kWave), 0, s, workspace, nblocks, n, out);
   return launch_status();
 }
