@@ -1,0 +1,152 @@
+"""Device-side CDAE batches (the CDAE counterpart of data/triplets.py).
+
+The reference keeps, per user, dense 0/1 vectors over the whole catalogue on the host
+(data/datasets/cdae_data_pipeline.py:22-48: four int32 masks per user — 19 GB at Yelp2018 size) and
+builds every batch from them in ``CDAEDataset.__getitem__`` (cdae_dataset.py:36-59), negative mask
+included (``np.random.choice(non-positives, neg_times * positives, replace=False)``, :20-34).  Each
+[B, I] float batch then crosses PCIe (39 MB per 256 users) — two orders of magnitude more time than
+the training step on MI355X.
+
+Here the interactions stay sparse (per-user train / valid / test item lists as CSR on the device) and
+the dense rows of a batch are materialised on the device right before the step, with the same keys
+the reference's DataLoader yields (``user_id, input_mask, negative_mask | valid_mask | test_mask``).
+Negative masks have the reference's law — exactly ``neg_times * positives`` distinct non-positive
+items per user, every subset equally likely (random keys + per-row order statistic) — but from the
+device RNG, so parity tests replay recorded masks instead (tests/test_gpu_cdae.py).
+"""
+import torch
+
+
+def _csr_from_pairs(rows, cols, num_rows):
+    order = torch.argsort(rows * (int(cols.max()) + 1 if cols.numel() else 1) + cols)
+    rows, cols = rows[order], cols[order]
+    ptr = torch.zeros(num_rows + 1, dtype=torch.int64, device=rows.device)
+    ptr[1:] = torch.cumsum(torch.bincount(rows, minlength=num_rows), 0)
+    return ptr, cols.contiguous()
+
+
+class CDAEInteractions:
+    """Per-user train / valid / test item lists (CSR, item ids ascending inside a user)."""
+
+    PARTS = ("train", "valid", "test")
+
+    def __init__(self, num_users, num_items, parts, device):
+        self.num_users, self.num_items, self.device = int(num_users), int(num_items), torch.device(device)
+        self._csr = {k: (p.to(self.device), i.to(self.device)) for k, (p, i) in parts.items()}
+
+    # -- constructors -----------------------------------------------------------------------
+    @classmethod
+    def from_split(cls, train_data, valid_data, test_data, device="cpu"):
+        """From the dicts ``CDAEDataPipeline.split`` returns (dense masks per user): the same
+        split, stored sparsely.  Users are the dict keys, assumed dense 0..U-1 like the
+        reference's ``nn.Embedding(num_users)`` lookup (models/cdae.py:49)."""
+        import numpy as np
+        users = sorted(train_data.keys())
+        num_items = len(next(iter(train_data.values()))["input_mask"])
+        parts = {}
+        for name, get in (("train", lambda u: train_data[u]["input_mask"]),
+                          ("valid", lambda u: valid_data[u]["valid_mask"]),
+                          ("test", lambda u: test_data[u]["test_mask"])):
+            ptr = np.zeros(len(users) + 1, dtype=np.int64)
+            idx = []
+            for k, u in enumerate(users):
+                nz = np.flatnonzero(get(u))
+                idx.append(nz)
+                ptr[k + 1] = ptr[k] + len(nz)
+            parts[name] = (torch.from_numpy(ptr), torch.from_numpy(np.concatenate(idx).astype(np.int64)))
+        return cls(len(users), num_items, parts, device)
+
+    @classmethod
+    def from_interactions(cls, user, item, num_users, num_items, seed=0, device=None):
+        """Straight from (user, item) pairs: each user's history is shuffled and cut 60/20/20 with
+        the reference's arithmetic (cdae_data_pipeline.py:30-32: ``int(0.8 n)`` train+valid,
+        of which ``int(0.75 .)`` train)."""
+        device = torch.device(device if device is not None else user.device)
+        user, item = user.to(device).long(), item.to(device).long()
+        key = torch.unique(user * num_items + item)                       # the pivot de-duplicates pairs
+        user, item = torch.div(key, num_items, rounding_mode="floor"), key % num_items
+        gen = torch.Generator(device=device).manual_seed(seed)
+        r = torch.rand(user.numel(), generator=gen, device=device)
+        order = torch.argsort(user.double() + r.double() * 0.999999)      # by user, random inside a user
+        user, item = user[order], item[order]
+        counts = torch.bincount(user, minlength=num_users)
+        start = torch.cumsum(counts, 0) - counts
+        pos = torch.arange(user.numel(), device=device) - start[user]     # rank inside the shuffled history
+        n = counts[user]
+        n_tv = torch.floor(0.8 * n.double()).long()                       # int(0.8 * len)
+        n_tr = torch.floor(0.75 * n_tv.double()).long()                   # int(0.75 * len(train_samples))
+        label = torch.where(pos < n_tr, 0, torch.where(pos < n_tv, 1, 2))
+        parts = {}
+        for k, name in enumerate(cls.PARTS):
+            m = label == k
+            parts[name] = _csr_from_pairs(user[m], item[m], num_users)
+        return cls(num_users, num_items, parts, device)
+
+    # -- access -------------------------------------------------------------------------------
+    def counts(self, part):
+        ptr, _ = self._csr[part]
+        return ptr[1:] - ptr[:-1]
+
+    def dense(self, part, users):
+        """[len(users), num_items] float32 0/1 rows of ``part`` ('train', 'valid', 'test' or
+        'train_valid' = train | valid, the test-time input of cdae_data_pipeline.py:38)."""
+        out = torch.zeros((users.numel(), self.num_items), dtype=torch.float32, device=self.device)
+        for p in (("train", "valid") if part == "train_valid" else (part,)):
+            ptr, idx = self._csr[p]
+            lo, cnt = ptr[users], ptr[users + 1] - ptr[users]
+            rows = torch.repeat_interleave(torch.arange(users.numel(), device=self.device), cnt)
+            offs = torch.arange(rows.numel(), device=self.device) - torch.repeat_interleave(torch.cumsum(cnt, 0) - cnt, cnt)
+            out[rows, idx[lo[rows] + offs]] = 1.0
+        return out
+
+
+class CDAEBatchLoader:
+    """Iterable of batches with the reference DataLoader's keys, tensors already on the device.
+
+    mode 'train': user_id, input_mask (train items), negative_mask
+    mode 'valid': user_id, input_mask (train items), valid_mask, negative_mask (avoids train + valid)
+    mode 'test' : user_id, input_mask (train + valid items), test_mask
+    """
+
+    def __init__(self, data: CDAEInteractions, mode="train", batch_size=32, neg_times=5, shuffle=False, seed=0):
+        if mode not in ("train", "valid", "test"):
+            raise ValueError(f"mode {mode!r}")
+        self.data, self.mode, self.batch_size, self.neg_times, self.shuffle = data, mode, int(batch_size), neg_times, shuffle
+        self._gen = torch.Generator(device=data.device).manual_seed(seed)
+
+    def __len__(self):
+        return (self.data.num_users + self.batch_size - 1) // self.batch_size
+
+    def negative_mask(self, positives):
+        """Exactly ``neg_times * positives`` distinct non-positive items per row, uniformly: the
+        items with the smallest of I i.i.d. random keys among the non-positives."""
+        n = (positives.sum(dim=1) * self.neg_times).long()
+        room = positives.shape[1] - positives.sum(dim=1).long()
+        if bool((n > room).any()):
+            # np.random.choice(..., replace=False) raises in the reference (cdae_dataset.py:27)
+            raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+        kmax = int(n.max()) if n.numel() else 0
+        if kmax == 0:
+            return torch.zeros_like(positives)
+        # float64 keys: with float32 a row of 38k keys holds dozens of ties, and a tie AT the
+        # threshold would break the exact count
+        keys = torch.rand(positives.shape, generator=self._gen, device=positives.device, dtype=torch.float64)
+        keys = torch.where(positives > 0, torch.full_like(keys, 2.0), keys)
+        smallest = torch.topk(keys, kmax, dim=1, largest=False, sorted=True).values
+        thr = smallest.gather(1, (n - 1).clamp_(min=0)[:, None])
+        return ((keys <= thr) & (n[:, None] > 0)).float()
+
+    def __iter__(self):
+        d = self.data
+        order = (torch.randperm(d.num_users, generator=self._gen, device=d.device) if self.shuffle
+                 else torch.arange(d.num_users, device=d.device))
+        for s in range(0, d.num_users, self.batch_size):
+            users = order[s:s + self.batch_size]
+            if self.mode == "train":
+                x = d.dense("train", users)
+                yield {"user_id": users, "input_mask": x, "negative_mask": self.negative_mask(x)}
+            elif self.mode == "valid":
+                x, v = d.dense("train", users), d.dense("valid", users)
+                yield {"user_id": users, "input_mask": x, "valid_mask": v, "negative_mask": self.negative_mask(x + v)}
+            else:
+                yield {"user_id": users, "input_mask": d.dense("train_valid", users), "test_mask": d.dense("test", users)}

@@ -60,8 +60,19 @@ def build(cfg):
             nu, ni, mean = (float(x) for x in str(synthetic).split("x"))
             df = make_frame(int(nu), int(ni), mean)
         pipe._load_df = lambda: df
-    df = pipe.preprocess()
     args.data_pipeline = pipe
+    if cfg.model_name == 'CDAE' and cfg.get("fast_loader"):
+        # sparse device-side store instead of the dense pivot + four dense masks per user
+        import torch
+        from .data.cdae_batches import CDAEInteractions
+        raw = pipe._load_df()
+        nu, ni = int(raw.user_id.max()) + 1, int(raw.business_id.max()) + 1
+        args.cdae_data = CDAEInteractions.from_interactions(
+            torch.from_numpy(raw.user_id.values.astype('int64')), torch.from_numpy(raw.business_id.values.astype('int64')),
+            nu, ni, seed=cfg.seed, device=cfg.device)
+        args.model_info = {'num_items': ni, 'num_users': nu}
+        return args
+    df = pipe.preprocess()
     if cfg.model_name == 'CDAE':
         from .data.datasets.cdae_dataset import CDAEDataset
         train_data, valid_data, test_data = pipe.split(df)
@@ -90,12 +101,18 @@ def train(cfg, args):
         nu = args.model_info['num_users']
         train_dataloader = EpochLoader(args.train_dataset.to_sampler(dev, nu, seed=cfg.seed), cfg.batch_size, cfg.shuffle)
         valid_dataloader = EpochLoader(args.valid_dataset.to_sampler(dev, nu, seed=cfg.seed + 1), cfg.batch_size, cfg.shuffle)
-    else:
+    elif not (cfg.get("fast_loader") and cfg.model_name == 'CDAE'):
         train_dataloader = DataLoader(args.train_dataset, batch_size=cfg.batch_size, shuffle=cfg.shuffle)
         valid_dataloader = DataLoader(args.valid_dataset, batch_size=cfg.batch_size, shuffle=cfg.shuffle)
     if cfg.model_name == 'CDAE':
         from .trainers.cdae_trainer import CDAETrainer
-        test_dataloader = DataLoader(args.test_dataset, batch_size=cfg.batch_size)
+        if cfg.get("fast_loader"):
+            from .data.cdae_batches import CDAEBatchLoader
+            mk = lambda mode, seed: CDAEBatchLoader(args.cdae_data, mode, cfg.batch_size, cfg.neg_times,
+                                                    shuffle=cfg.shuffle and mode != 'test', seed=seed)
+            train_dataloader, valid_dataloader, test_dataloader = mk('train', cfg.seed), mk('valid', cfg.seed + 1), mk('test', 0)
+        else:
+            test_dataloader = DataLoader(args.test_dataset, batch_size=cfg.batch_size)
         trainer = CDAETrainer(cfg, args.model_info['num_items'], args.model_info['num_users'])
         trainer.run(train_dataloader, valid_dataloader)
         trainer.load_best_model()
