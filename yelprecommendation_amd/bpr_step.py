@@ -25,7 +25,7 @@ from .user_shard import sharded_item_exchange
 
 # below this many triplets per step the float-atomic form wins (3 launches instead of 8; the
 # atomic ceiling only bites at large batches) — measured crossover ~100 k on MI355X
-AUTO_PULL_MIN_BATCH = 98304
+AUTO_PULL_MIN_BATCH = 114688   # measured crossover at Yelp2018 shape (atomic 96 us vs pull 100 us at 98,304; 116 vs 102 us at 131,072)
 
 IMPL_NAMES = {
     "auto": "auto: atomic scatter below %d triplets per step, pull above" % AUTO_PULL_MIN_BATCH,
