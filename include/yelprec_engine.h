@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 14
+#define YR_ENGINE_VERSION 15
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -330,6 +330,14 @@ int yr_adam_dense(float *p, float *g, float *m, float *v, int64_t n,
                   int mode, int zero_grad, void *stream);
 
 /* Dense SGD (no momentum): p -= lr * (g + wd * p)   (base_trainer.py:39-40). */
+/* yr_adam_dense_multi: the same update for up to YR_ADAM_MULTI_MAX tensors in one launch (the small
+ * weight matrices and biases beside an embedding table; all at the same step count).  p / g / m / v
+ * / n are HOST arrays of `count` device pointers / element counts; no alignment requirement. */
+#define YR_ADAM_MULTI_MAX 16
+int yr_adam_dense_multi(float *const *p, float *const *g, float *const *m, float *const *v,
+                        const int64_t *n, int count, double lr, double step_size, double bc2_sqrt,
+                        double beta1, double beta2, double eps, double weight_decay, int mode,
+                        int zero_grad, void *stream);
 int yr_sgd_dense(float *p, float *g, int64_t n, double lr, double weight_decay,
                  int zero_grad, void *stream);
 

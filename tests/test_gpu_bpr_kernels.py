@@ -108,6 +108,29 @@ def test_adam_dense(device, mode):
     np.testing.assert_allclose(dv.cpu().numpy(), v, rtol=1e-5, atol=1e-12)
 
 
+@pytest.mark.parametrize("mode", ["adam", "adamw"])
+def test_adam_dense_multi_equals_single_launches(device, mode):
+    """yr_adam_dense_multi (one launch for the small tensors of a model) is bit-identical to one
+    yr_adam_dense per tensor: odd sizes, an empty tensor, more tensors than one launch takes."""
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(3)
+    sizes = [1, 7, 64 * 64, 4099, 0, 128] + [33] * 14                       # 20 tensors > ADAM_MULTI_MAX
+    mk = lambda n: torch.from_numpy(rs.standard_normal(n).astype(np.float32)).to(device)
+    A = [(mk(n), mk(n), mk(n).abs() * 0, mk(n).abs() * 0) for n in sizes]
+    B = [tuple(t.clone() for t in tup) for tup in A]
+    kw = dict(weight_decay=1e-2, decoupled=(mode == "adamw"))
+    for step in range(1, 4):
+        for (p, g, m, v), (p2, g2, m2, v2) in zip(A, B):
+            new_g = mk(p.numel())
+            g.copy_(new_g); g2.copy_(new_g)
+            if p.numel():
+                engine.adam_dense(p, g, m, v, step, 1e-3, zero_grad=True, **kw)
+        engine.adam_dense_multi(B, step, 1e-3, zero_grad=True, **kw)
+    for ta, tb in zip(A, B):
+        for x, y in zip(ta, tb):
+            assert torch.equal(x, y)
+
+
 def test_sgd_dense(device):
     from yelprecommendation_amd import engine
     rs = np.random.RandomState(12)

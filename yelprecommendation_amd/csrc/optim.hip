@@ -55,6 +55,30 @@ __global__ __launch_bounds__(kBlock) void adam_dense_kernel(float* __restrict__ 
   }
 }
 
+// Several small tensors in one launch (blockIdx.y = tensor): the weight matrices and biases next
+// to an embedding table cost a launch each otherwise, ~5 us apiece for a few KB of work.
+struct AdamMulti {
+  float* p[YR_ADAM_MULTI_MAX];
+  float* g[YR_ADAM_MULTI_MAX];
+  float* m[YR_ADAM_MULTI_MAX];
+  float* v[YR_ADAM_MULTI_MAX];
+  int64_t n[YR_ADAM_MULTI_MAX];
+};
+
+template <bool DECOUPLED, bool ZERO_GRAD>
+__global__ __launch_bounds__(kBlock) void adam_dense_multi_kernel(AdamMulti t, AdamScalars c) {
+  const int k = blockIdx.y;
+  float* p = t.p[k]; float* g = t.g[k]; float* m = t.m[k]; float* v = t.v[k];
+  const int64_t n = t.n[k];
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    float P = p[i], G = g[i], M = m[i], V = v[i];
+    adam_element<DECOUPLED>(P, G, M, V, c);
+    p[i] = P; m[i] = M; v[i] = V;
+    if (ZERO_GRAD) g[i] = 0.0f;
+  }
+}
+
 template <bool ZERO_GRAD>
 __global__ __launch_bounds__(kBlock) void sgd_dense_kernel(float* __restrict__ p, float* __restrict__ g,
                                                            int64_t n4, int64_t n, float lr, float wd) {
@@ -121,6 +145,46 @@ extern "C" int yr_adam_dense(float* p, float* g, float* m, float* v, int64_t n, 
     if (zero_grad) YR_LAUNCH_ADAM(false, true); else YR_LAUNCH_ADAM(false, false);
   }
 #undef YR_LAUNCH_ADAM
+  return launch_status();
+}
+
+extern "C" int yr_adam_dense_multi(float* const* p, float* const* g, float* const* m, float* const* v,
+                                   const int64_t* n, int count, double lr, double step_size, double bc2_sqrt,
+                                   double beta1, double beta2, double eps, double weight_decay, int mode,
+                                   int zero_grad, void* stream) {
+  if (count < 0 || count > YR_ADAM_MULTI_MAX) return YR_ERR_BADARG;
+  if (count == 0) return 0;
+  if (!p || !g || !m || !v || !n) return YR_ERR_BADARG;
+  if (mode != YR_OPT_ADAM && mode != YR_OPT_ADAMW) return YR_ERR_UNSUPPORTED;
+  AdamMulti t{};
+  int64_t longest = 0;
+  for (int k = 0; k < count; ++k) {
+    if (n[k] < 0 || (n[k] > 0 && (!p[k] || !g[k] || !m[k] || !v[k]))) return YR_ERR_BADARG;
+    t.p[k] = p[k]; t.g[k] = g[k]; t.m[k] = m[k]; t.v[k] = v[k]; t.n[k] = n[k];
+    if (n[k] > longest) longest = n[k];
+  }
+  if (longest == 0) return 0;
+  AdamScalars c;
+  c.decay_mul = (float)(1.0 - lr * weight_decay);
+  c.neg_step = (float)(-step_size);
+  c.bc2_sqrt = (float)bc2_sqrt;
+  c.one_m_b1 = (float)(1.0 - beta1);
+  c.beta2 = (float)beta2;
+  c.one_m_b2 = (float)(1.0 - beta2);
+  c.eps = (float)eps;
+  c.wd = (float)weight_decay;
+  int gx = grid_for(longest, kBlock);
+  if (gx > 1024) gx = 1024;
+  const dim3 grid((unsigned)gx, (unsigned)count);
+  hipStream_t s = (hipStream_t)stream;
+#define YR_LAUNCH_ADAM_MULTI(DEC, ZG) \
+  hipLaunchKernelGGL((adam_dense_multi_kernel<DEC, ZG>), grid, dim3(kBlock), 0, s, t, c)
+  if (mode == YR_OPT_ADAMW) {
+    if (zero_grad) YR_LAUNCH_ADAM_MULTI(true, true); else YR_LAUNCH_ADAM_MULTI(true, false);
+  } else {
+    if (zero_grad) YR_LAUNCH_ADAM_MULTI(false, true); else YR_LAUNCH_ADAM_MULTI(false, false);
+  }
+#undef YR_LAUNCH_ADAM_MULTI
   return launch_status();
 }
 

@@ -226,14 +226,17 @@ def ngcf_dense_fwd(E, Z, W1, W2, out=None):
     return out
 
 
-def ngcf_dense_bwd(dEout, Eout, E, Z, W1, W2, dE, dW1, dW2, dZ=None):
-    """Backward of :func:`ngcf_dense_fwd`: dE += ..., dW1 += ..., dW2 += ..., returns dZ."""
+def ngcf_dense_bwd(dEout, Eout, E, Z, W1, W2, dE, dW1, dW2, dZ=None, W1T=None, W2T=None):
+    """Backward of :func:`ngcf_dense_fwd`: dE += ..., dW1 += ..., dW2 += ..., returns dZ.
+    ``W1T / W2T``: the transposed weights if the caller already has them (one batched transpose
+    for all layers instead of two small launches per layer)."""
     lib = _lib.load()
     n, d = E.shape
     f32 = torch.float32
     if dZ is None:
         dZ = torch.empty_like(E)
-    W1T, W2T = W1.t().contiguous(), W2.t().contiguous()      # [in, out] layout for the data-gradient GEMM
+    if W1T is None:
+        W1T, W2T = W1.t().contiguous(), W2.t().contiguous()  # [in, out] layout for the data-gradient GEMM
     check(lib.yr_ngcf_dense_bwd_weight(_dev(dEout, f32, "dEout"), _dev(Eout, f32, "Eout"), _dev(E, f32, "E"),
                                        _dev(Z, f32, "Z"), n, d, _dev(dW1, f32, "dW1"), _dev(dW2, f32, "dW2"),
                                        _stream()), "yr_ngcf_dense_bwd_weight")
@@ -506,6 +509,32 @@ def adam_dense(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_de
                             float(lr), float(step_size), float(bc2_sqrt), float(beta1), float(beta2),
                             float(eps), float(weight_decay), OPT_ADAMW if decoupled else OPT_ADAM,
                             1 if zero_grad else 0, _stream()), "yr_adam_dense")
+
+
+ADAM_MULTI_MAX = 16
+
+
+def adam_dense_multi(tensors, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0,
+                     decoupled=False, zero_grad=False):
+    """The same Adam/AdamW step for several (p, g, m, v) tuples at the same step count in ONE launch
+    per ADAM_MULTI_MAX tensors — for the small weight matrices and biases of a model."""
+    import ctypes
+    lib = _lib.load()
+    step_size, bc2_sqrt = adam_scalars(step, lr, beta1, beta2)
+    f32 = torch.float32
+    for s0 in range(0, len(tensors), ADAM_MULTI_MAX):
+        group = tensors[s0:s0 + ADAM_MULTI_MAX]
+        cols = []
+        for k, name in enumerate("pgmv"):
+            cols.append((ctypes.c_void_p * len(group))(*[_dev(t[k], f32, name) for t in group]))
+        for p, g, m, v in group:
+            if not (p.numel() == g.numel() == m.numel() == v.numel()):
+                raise EngineError("p/g/m/v sizes differ")
+        counts = (ctypes.c_int64 * len(group))(*[t[0].numel() for t in group])
+        check(lib.yr_adam_dense_multi(cols[0], cols[1], cols[2], cols[3], counts, len(group), float(lr),
+                                      float(step_size), float(bc2_sqrt), float(beta1), float(beta2), float(eps),
+                                      float(weight_decay), OPT_ADAMW if decoupled else OPT_ADAM,
+                                      1 if zero_grad else 0, _stream()), "yr_adam_dense_multi")
 
 
 def sgd_dense(p, g, lr, weight_decay=0.0, zero_grad=False):

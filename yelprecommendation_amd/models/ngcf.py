@@ -66,15 +66,20 @@ class _NGCFScores(torch.autograd.Function):
         W1s, W2s = weights[:K], weights[K:]
         gpos = gpos.contiguous()
         # gradient of every layer buffer from the scores (dense scatter-add, like index_add_)
-        dlayers = [_zero_like(E) for E in layers]
+        # one zero-fill for all layer gradients, one for all weight gradients, one batched transpose
+        # for all weights: these were ~25 launch-bound ATen kernels per step
+        dstack = torch.zeros((K + 1,) + tuple(layers[0].shape), dtype=layers[0].dtype, device=layers[0].device)
+        dlayers = list(dstack.unbind(0))
         engine.ngcf_score_backward(layers, dlayers, nu, user_id, pos_ids, neg_ids if ctx.has_neg else None,
                                    gpos, gneg.contiguous() if ctx.has_neg else None, err_flag=ctx.err_flag)
+        dWstack = torch.zeros((2 * K,) + tuple(W1s[0].shape), dtype=W1s[0].dtype, device=W1s[0].device) if K else None
+        WT = torch.stack(list(weights)).transpose(1, 2).contiguous() if K else None
         dW1s, dW2s = [None] * K, [None] * K
         for k in range(K - 1, -1, -1):
-            dW1s[k], dW2s[k] = _zero_like(W1s[k]), _zero_like(W2s[k])
+            dW1s[k], dW2s[k] = dWstack[k], dWstack[K + k]
             # dlayers[k] += dA + dH * Z ; dZ = dA + dH * E ; then dlayers[k] += L^T dZ (L symmetric)
             dZ = engine.ngcf_dense_bwd(dlayers[k + 1], layers[k + 1], layers[k], Zs[k], W1s[k], W2s[k],
-                                       dlayers[k], dW1s[k], dW2s[k])
+                                       dlayers[k], dW1s[k], dW2s[k], W1T=WT[k], W2T=WT[K + k])
             engine.spmm_csr(graph, dZ, out=dlayers[k], accumulate=True)
         return (None, None, None, None, None, None, dlayers[0], *dW1s, *dW2s)
 
