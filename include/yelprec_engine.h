@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 15
+#define YR_ENGINE_VERSION 16
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -210,7 +210,9 @@ int yr_ngcf_dense_bwd_weight(const float *dEout, const float *Eout, const float 
  *   (dy @ W) and its weight gradient (dy^T @ x: transA = 1).
  * yr_cdae_hidden_init: zpre[b,:] = bias + V[user[b],:]   (b_h + user_nodes(user_id), cdae.py:49).
  * yr_dropout: out = rnd >= p ? x / (1 - p) : 0, rnd uniform [0,1) supplied by the caller (nn.Dropout).
- * yr_sigmoid / yr_sigmoid_bwd: x = sigmoid(x) in place;  g *= y (1 - y) in place.
+ * yr_dropout_seeded: the same with the uniforms drawn in the kernel (Philox4x32-10 keyed by `seed`,
+ *   counter = index of the 4-element group): nothing but x is read.  x / out 16-byte aligned.
+ * yr_sigmoid / yr_sigmoid_bwd: x = sigmoid(x) in place;  g = dy * y (1 - y)  (g may alias dy).
  * yr_colsum: out[c] (+)= sum_r X[r,c]                    (bias gradients).
  * yr_row_scatter_add: dV[user[b],:] += G[b,:]            (embedding_dense_backward of user_nodes).
  * yr_nsbce_fwd: NSBCELoss — positions with target + negative_mask != 0 (all positions when
@@ -225,7 +227,8 @@ int yr_cdae_hidden_init(float *zpre, const float *bias, const float *V, const in
                         int64_t B, int H, int64_t num_users, int32_t *err_flag, void *stream);
 int yr_dropout(const float *x, const float *rnd, double p, int64_t n, float *out, void *stream);
 int yr_sigmoid(float *x, int64_t n, void *stream);
-int yr_sigmoid_bwd(float *g, const float *y, int64_t n, void *stream);
+int yr_dropout_seeded(const float *x, uint64_t seed, double p, int64_t n, float *out, void *stream);
+int yr_sigmoid_bwd(const float *dy, const float *y, float *g, int64_t n, void *stream);
 int yr_colsum(const float *X, int64_t rows, int64_t cols, float *out, int accumulate, void *stream);
 int yr_row_scatter_add(const float *G, const int64_t *user, int64_t B, int H, int64_t num_users,
                        float *dV, void *stream);

@@ -133,6 +133,38 @@ def test_dropout_statistics_and_eval_identity(g, tmp_path, device):
     assert model.add_noise(x) is x
 
 
+def test_seeded_dropout_is_a_fair_reproducible_mask(device):
+    """yr_dropout_seeded (Philox in the kernel): same (seed, shape) -> same mask, another seed ->
+    another mask, keep rate 1 - p in every row and column block, no correlation between neighbouring
+    elements, ragged sizes (scalar tail), and the explicit-uniform kernel's semantics (x / (1 - p))."""
+    from yelprecommendation_amd import engine
+    from yelprecommendation_amd.utils import set_seed
+    x = torch.full((512, 4099), 3.0, device=device)                      # 4099: tail of 3 elements per ... flat index
+    a = engine.dropout_seeded(x, 1234, 0.6)
+    b = engine.dropout_seeded(x, 1234, 0.6)
+    c = engine.dropout_seeded(x, 1235, 0.6)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert set(torch.unique(a).tolist()) <= {0.0, 7.5}
+    keep = (a != 0).float()
+    assert abs(keep.mean().item() - 0.4) < 0.005
+    assert (keep.mean(1) - 0.4).abs().max().item() < 0.05 and (keep.mean(0) - 0.4).abs().max().item() < 0.1
+    k = keep.flatten()
+    for lag in (1, 2, 3, 4, 4099):
+        corr = ((k[:-lag] - 0.4) * (k[lag:] - 0.4)).mean().item() / 0.24
+        assert abs(corr) < 0.01, (lag, corr)
+    small = torch.ones(7, device=device)                                   # n < 4 groups, only tails
+    assert set(torch.unique(engine.dropout_seeded(small, 5, 0.5)).tolist()) <= {0.0, 2.0}
+    # the model draws its seed from torch's generator: set_seed pins the masks
+    from yelprecommendation_amd.models.cdae import CDAE
+    from yelprecommendation_amd.utils import make_config
+    model = CDAE(make_config("CDAE", hidden_size=8, device="cuda", model_dir="/tmp/yr_cdae_do"), 4099, 10)
+    model.train()
+    set_seed(7); m1 = model.add_noise(x)
+    set_seed(7); m2 = model.add_noise(x)
+    m3 = model.add_noise(x)
+    assert torch.equal(m1, m2) and not torch.equal(m1, m3)
+
+
 def test_trainer_run_matches_reference(g, tmp_path, device):
     from yelprecommendation_amd.trainers import CDAETrainer
     t = CDAETrainer(_cfg(g, tmp_path, negative_sampling=True), int(g["num_items"]), int(g["num_users"]))

@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
-ENGINE_VERSION = 15
+ENGINE_VERSION = 16
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -41,7 +41,8 @@ SIGNATURES = {
     "yr_cdae_hidden_init": [_p, _p, _p, _p, _i64, _int, _i64, _p, _p],
     "yr_dropout": [_p, _p, _d, _i64, _p, _p],
     "yr_sigmoid": [_p, _i64, _p],
-    "yr_sigmoid_bwd": [_p, _p, _i64, _p],
+    "yr_dropout_seeded": [_p, C.c_uint64, _d, _i64, _p, _p],
+    "yr_sigmoid_bwd": [_p, _p, _p, _i64, _p],
     "yr_colsum": [_p, _i64, _i64, _p, _int, _p],
     "yr_row_scatter_add": [_p, _p, _i64, _int, _i64, _p, _p],
     "yr_nsbce_fwd": [_p, _p, _p, _i64, _p, _p, _p],

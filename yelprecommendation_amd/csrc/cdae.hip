@@ -278,17 +278,53 @@ __global__ __launch_bounds__(kBlock) void dropout_kernel(const float* __restrict
     out[e] = rnd[e] >= p ? x[e] * scale : 0.0f;
 }
 
+// nn.Dropout with the uniforms drawn in the kernel: Philox4x32-10 keyed by `seed`, counter = index
+// of the float4 group, so the mask depends on (seed, position) only — no 4-byte-per-element random
+// tensor is written and read back.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
+    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+    key.x += 0x9E3779B9u;
+    key.y += 0xBB67AE85u;
+  }
+  return ctr;
+}
+
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(kBlock) void dropout_seeded_kernel(const float* __restrict__ x, uint64_t seed, float p,
+                                                                float scale, int64_t n, float* __restrict__ out) {
+  const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+  const int64_t n4 = (n + 3) / 4;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < n4; q += stride) {
+    const uint4 r = philox4x32_10(make_uint4((uint32_t)q, (uint32_t)(q >> 32), 0u, 0u), key);
+    const float u[4] = {u01(r.x), u01(r.y), u01(r.z), u01(r.w)};
+    const int64_t e = 4 * q;
+    if (e + 3 < n) {
+      const float4 v = *reinterpret_cast<const float4*>(x + e);
+      *reinterpret_cast<float4*>(out + e) = make_float4(u[0] >= p ? v.x * scale : 0.0f, u[1] >= p ? v.y * scale : 0.0f,
+                                                        u[2] >= p ? v.z * scale : 0.0f, u[3] >= p ? v.w * scale : 0.0f);
+    } else {
+      for (int k = 0; e + k < n; ++k) out[e + k] = u[k] >= p ? x[e + k] * scale : 0.0f;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void sigmoid_kernel(float* __restrict__ x, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride)
     x[e] = 1.0f / (1.0f + expf(-x[e]));
 }
 
-// g *= y (1 - y)        (sigmoid backward through the OUTPUT y)
-__global__ __launch_bounds__(kBlock) void sigmoid_bwd_kernel(float* __restrict__ g, const float* __restrict__ y,
-                                                             int64_t n) {
+// g = dy * y (1 - y)     (sigmoid backward through the OUTPUT y; g may be dy itself)
+__global__ __launch_bounds__(kBlock) void sigmoid_bwd_kernel(const float* dy, const float* __restrict__ y,
+                                                             float* g, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) g[e] *= y[e] * (1.0f - y[e]);
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) g[e] = dy[e] * (y[e] * (1.0f - y[e]));
 }
 
 // out[c] (+)= sum_r X[r, c]        (bias gradients)
@@ -486,11 +522,20 @@ extern "C" int yr_sigmoid(float* x, int64_t n, void* stream) {
   return launch_status();
 }
 
-extern "C" int yr_sigmoid_bwd(float* g, const float* y, int64_t n, void* stream) {
+extern "C" int yr_sigmoid_bwd(const float* dy, const float* y, float* g, int64_t n, void* stream) {
   if (n < 0) return YR_ERR_BADARG;
   if (n == 0) return 0;
-  if (!g || !y) return YR_ERR_BADARG;
-  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, (hipStream_t)stream, g, y, n);
+  if (!dy || !g || !y) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ew_grid(n)), dim3(kBlock), 0, (hipStream_t)stream, dy, y, g, n);
+  return launch_status();
+}
+
+extern "C" int yr_dropout_seeded(const float* x, uint64_t seed, double p, int64_t n, float* out, void* stream) {
+  if (n < 0 || p < 0.0 || p >= 1.0) return YR_ERR_BADARG;
+  if (n == 0) return 0;
+  if (!x || !out || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15u)) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(dropout_seeded_kernel, dim3(ew_grid((n + 3) / 4)), dim3(kBlock), 0, (hipStream_t)stream, x, seed,
+                     (float)p, (float)(1.0 / (1.0 - p)), n, out);
   return launch_status();
 }
 

@@ -297,11 +297,27 @@ def sigmoid_(x):
     return x
 
 
-def sigmoid_bwd_(g, y):
+def sigmoid_bwd(dy, y, out=None):
+    """dy * y * (1 - y); ``out`` may be ``dy`` itself (in place) or omitted (new tensor)."""
     lib = _lib.load()
-    check(lib.yr_sigmoid_bwd(_dev(g, torch.float32, "g"), _dev(y, torch.float32, "y"), g.numel(), _stream()),
-          "yr_sigmoid_bwd")
-    return g
+    if out is None:
+        out = torch.empty_like(dy)
+    check(lib.yr_sigmoid_bwd(_dev(dy, torch.float32, "dy"), _dev(y, torch.float32, "y"), _dev(out, torch.float32, "g"),
+                             dy.numel(), _stream()), "yr_sigmoid_bwd")
+    return out
+
+
+def sigmoid_bwd_(g, y):
+    return sigmoid_bwd(g, y, out=g)
+
+
+def dropout_seeded(x, seed, p):
+    """nn.Dropout(p) in training mode with the mask drawn inside the kernel from (seed, position)."""
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    check(lib.yr_dropout_seeded(_dev(x, torch.float32, "x"), int(seed) & 0xFFFFFFFFFFFFFFFF, float(p), x.numel(),
+                                out.data_ptr(), _stream()), "yr_dropout_seeded")
+    return out
 
 
 def colsum(X, out=None, accumulate=False):

@@ -44,9 +44,9 @@ class _CDAEForward(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         user_id, x_in, z, y, Wh, Wo, V = ctx.saved_tensors
-        g = dy.contiguous().clone()
-        if ctx.output_act == engine.ACT_SIGMOID:
-            engine.sigmoid_bwd_(g, y)                        # d pre-activation of the output layer
+        dy = dy.contiguous()
+        # d pre-activation of the output layer (a fresh buffer: dy belongs to autograd)
+        g = engine.sigmoid_bwd(dy, y) if ctx.output_act == engine.ACT_SIGMOID else dy
         dWo = engine.gemm_f32(g, z, transA=True)             # [I, H] = g^T z
         dbo = engine.colsum(g)
         dz = engine.gemm_f32(g, Wo, split_k=_split_k(g.shape[1]))       # [B, H] = g Wo
@@ -104,11 +104,13 @@ class CDAE(BaseModel):
 
     def add_noise(self, x):
         """reference models/cdae.py:43-44: nn.Dropout(p) — inverted dropout in training mode,
-        identity in eval mode.  The uniform draws come from torch's generator; the masking and
-        1/(1-p) scaling run in the HIP kernel."""
+        identity in eval mode.  One 62-bit seed per call comes from torch's (CPU) generator, so
+        ``set_seed`` fixes the masks; the uniforms themselves are Philox draws inside the HIP
+        kernel (no [B, I] random tensor).  ``engine.dropout(x, rnd, p)`` takes explicit uniforms."""
         if not self.training or self.corruption_level == 0:
             return x
-        return engine.dropout(x.contiguous(), torch.rand_like(x), self.corruption_level)
+        seed = int(torch.randint(0, 1 << 62, (1,)).item())
+        return engine.dropout_seeded(x.contiguous(), seed, self.corruption_level)
 
     def encode_decode(self, user_id, x_in):
         """forward() on an already-corrupted input (used by tests that replay recorded masks)."""
