@@ -173,7 +173,7 @@ def main():
 
     if rank == 0 and world == 1 and args.sweep:
         sweep = {}
-        for b in (4096, 65536, 262144):
+        for b in (32, 4096, 65536, 262144):
             uu, pp, nn = (t[:b].contiguous() for t in pool[0])
             for _ in range(5):
                 step.step(uu, pp, nn)
