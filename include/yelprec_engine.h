@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 16
+#define YR_ENGINE_VERSION 17
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -343,6 +343,23 @@ int yr_adam_dense_multi(float *const *p, float *const *g, float *const *m, float
                         int zero_grad, void *stream);
 int yr_sgd_dense(float *p, float *g, int64_t n, double lr, double weight_decay,
                  int zero_grad, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * CDAE batches on the device      (reference data/datasets/cdae_dataset.py:20-59, which builds the
+ *   dense rows and the negative mask of every user on the host)
+ * yr_csr_rows_to_dense: out[b, :] (float32 [B, num_items]) = 0/1 row of user users[b] from a per-user
+ *   item CSR (ptr [num_users+1] / idx, int64); accumulate != 0 ORs onto the existing rows.
+ * yr_negative_mask: out[b, :] = exactly neg_times * (number of positives[b, :] > 0) distinct items with
+ *   positives[b, i] <= 0, every subset equally likely (np.random.choice(.., replace=False),
+ *   cdae_dataset.py:20-34); i.i.d. 64-bit Philox keys per (seed, row, item), the smallest win.  A row
+ *   that asks for more negatives than it has non-positives raises YR_FLAG_BAD_ITEM in err_flag (the
+ *   reference raises ValueError) and takes them all.
+ * ------------------------------------------------------------------------- */
+int yr_csr_rows_to_dense(const int64_t *ptr, const int64_t *idx, const int64_t *users, int64_t B,
+                         int64_t num_users, int64_t num_items, int accumulate, float *out,
+                         int32_t *err_flag, void *stream);
+int yr_negative_mask(const float *positives, int64_t B, int64_t num_items, int neg_times, uint64_t seed,
+                     float *out, int32_t *err_flag, void *stream);
 
 #ifdef __cplusplus
 }

@@ -241,3 +241,48 @@ def test_config5_shape_step_matches_oracle(device, tmp_path):
     np.testing.assert_allclose(loss.item(), want, rtol=1e-5)
     for p, r in zip(model.parameters(), ref.params):
         np.testing.assert_allclose(p.detach().cpu().numpy(), r, rtol=1e-3, atol=2e-6)
+
+
+def test_device_batches_match_host_definitions(device):
+    """yr_csr_rows_to_dense / yr_negative_mask behind data/cdae_batches.py: dense rows identical to
+    the torch (CPU) construction; negative masks with the reference's law — exact count, never a
+    positive, uniform over the non-positives, reproducible per seed — on ragged catalogue sizes."""
+    from yelprecommendation_amd import engine
+    from yelprecommendation_amd.data.cdae_batches import CDAEBatchLoader, CDAEInteractions
+    rs = np.random.RandomState(0)
+    nu, ni = 300, 4099
+    u = np.repeat(np.arange(nu), 25); i = rs.randint(0, ni, size=u.shape[0])
+    cpu = CDAEInteractions.from_interactions(torch.from_numpy(u), torch.from_numpy(i), nu, ni, seed=3, device="cpu")
+    gpu = CDAEInteractions(nu, ni, {k: cpu._csr[k] for k in CDAEInteractions.PARTS}, device)
+    users = torch.from_numpy(rs.permutation(nu)[:77].astype(np.int64))
+    for part in ("train", "valid", "test", "train_valid"):
+        torch.testing.assert_close(gpu.dense(part, users.to(device)).cpu(), cpu.dense(part, users), rtol=0, atol=0)
+    for mode in ("train", "valid"):
+        batches = list(CDAEBatchLoader(gpu, mode, batch_size=64, neg_times=5, seed=11))
+        again = list(CDAEBatchLoader(gpu, mode, batch_size=64, neg_times=5, seed=11))
+        other = list(CDAEBatchLoader(gpu, mode, batch_size=64, neg_times=5, seed=12))
+        assert sum(b["user_id"].numel() for b in batches) == nu
+        for b, a, o in zip(batches, again, other):
+            pos = b["input_mask"] + (b["valid_mask"] if mode == "valid" else 0)
+            neg = b["negative_mask"]
+            assert set(neg.unique().tolist()) <= {0.0, 1.0}
+            assert float((neg * pos).sum().item()) == 0.0
+            torch.testing.assert_close(neg.sum(1), 5 * pos.sum(1))
+            assert torch.equal(neg, a["negative_mask"]) and not torch.equal(neg, o["negative_mask"])
+    # uniformity over the non-positives (one row, many seeds) and the two edge cases
+    pos = torch.zeros(1, 133, device=device); pos[0, ::19] = 1                    # 7 positives, 126 non-positives
+    hits = sum(engine.negative_mask(pos, 3, seed) for seed in range(3000))[0]
+    assert float((hits * pos[0]).sum().item()) == 0.0
+    freq = hits[pos[0] == 0] / 3000.0                                              # expected 21 / 126
+    assert float((freq - 21 / 126).abs().max().item()) < 0.035
+    assert float(engine.negative_mask(torch.zeros(2, 50, device=device), 4, 1).sum().item()) == 0.0
+    flag = engine.new_error_flag(device)
+    crowded = torch.ones(1, 10, device=device); crowded[0, 0] = 0
+    out = engine.negative_mask(crowded, 2, 1, err_flag=flag)
+    assert int(flag.item()) == engine.FLAG_BAD_ITEM and float(out.sum().item()) == 1.0
+    loader = CDAEBatchLoader(CDAEInteractions(1, 10, {"train": (torch.tensor([0, 9]), torch.arange(1, 10)),
+                                                       "valid": (torch.tensor([0, 0]), torch.zeros(0, dtype=torch.int64)),
+                                                       "test": (torch.tensor([0, 0]), torch.zeros(0, dtype=torch.int64))},
+                                              device), "train", 4, neg_times=2)
+    with pytest.raises(ValueError):
+        list(loader)

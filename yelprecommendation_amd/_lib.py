@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
-ENGINE_VERSION = 16
+ENGINE_VERSION = 17
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -61,6 +61,8 @@ SIGNATURES = {
     "yr_bpr_loss_bwd": [_p, _p, _p, _f, _i64, _p, _p, _p],
     "yr_adam_dense": [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _d, _d, _int, _int, _p],
     "yr_adam_dense_multi": [_p, _p, _p, _p, _p, _int, _d, _d, _d, _d, _d, _d, _d, _int, _int, _p],
+    "yr_csr_rows_to_dense": [_p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p],
+    "yr_negative_mask": [_p, _i64, _i64, _int, C.c_uint64, _p, _p, _p],
     "yr_sgd_dense": [_p, _p, _i64, _d, _d, _int, _p],
 }
 

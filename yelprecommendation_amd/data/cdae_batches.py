@@ -13,8 +13,13 @@ the reference's DataLoader yields (``user_id, input_mask, negative_mask | valid_
 Negative masks have the reference's law — exactly ``neg_times * positives`` distinct non-positive
 items per user, every subset equally likely (random keys + per-row order statistic) — but from the
 device RNG, so parity tests replay recorded masks instead (tests/test_gpu_cdae.py).
+
+On the GPU both pieces are HIP kernels (``yr_csr_rows_to_dense``, ``yr_negative_mask``:
+csrc/cdae_batches.hip); on CPU tensors (host-logic tests) the same definitions run as torch ops.
 """
 import torch
+
+from .. import engine
 
 
 def _csr_from_pairs(rows, cols, num_rows):
@@ -90,8 +95,16 @@ class CDAEInteractions:
     def dense(self, part, users):
         """[len(users), num_items] float32 0/1 rows of ``part`` ('train', 'valid', 'test' or
         'train_valid' = train | valid, the test-time input of cdae_data_pipeline.py:38)."""
+        parts = ("train", "valid") if part == "train_valid" else (part,)
+        if self.device.type == "cuda":
+            out = None
+            for p in parts:
+                ptr, idx = self._csr[p]
+                out = engine.csr_rows_to_dense(ptr, idx, users.contiguous(), self.num_items, out=out,
+                                               accumulate=out is not None)
+            return out
         out = torch.zeros((users.numel(), self.num_items), dtype=torch.float32, device=self.device)
-        for p in (("train", "valid") if part == "train_valid" else (part,)):
+        for p in parts:
             ptr, idx = self._csr[p]
             lo, cnt = ptr[users], ptr[users + 1] - ptr[users]
             rows = torch.repeat_interleave(torch.arange(users.numel(), device=self.device), cnt)
@@ -113,6 +126,8 @@ class CDAEBatchLoader:
             raise ValueError(f"mode {mode!r}")
         self.data, self.mode, self.batch_size, self.neg_times, self.shuffle = data, mode, int(batch_size), neg_times, shuffle
         self._gen = torch.Generator(device=data.device).manual_seed(seed)
+        self._seeds = torch.Generator().manual_seed(seed)          # host generator: per-batch kernel seeds
+        self._flag = engine.new_error_flag(data.device) if data.device.type == "cuda" else None
 
     def __len__(self):
         return (self.data.num_users + self.batch_size - 1) // self.batch_size
@@ -120,6 +135,9 @@ class CDAEBatchLoader:
     def negative_mask(self, positives):
         """Exactly ``neg_times * positives`` distinct non-positive items per row, uniformly: the
         items with the smallest of I i.i.d. random keys among the non-positives."""
+        if positives.is_cuda:
+            seed = int(torch.randint(0, 1 << 62, (1,), generator=self._seeds).item())
+            return engine.negative_mask(positives.contiguous(), self.neg_times, seed, err_flag=self._flag)
         n = (positives.sum(dim=1) * self.neg_times).long()
         room = positives.shape[1] - positives.sum(dim=1).long()
         if bool((n > room).any()):
@@ -150,3 +168,8 @@ class CDAEBatchLoader:
                 yield {"user_id": users, "input_mask": x, "valid_mask": v, "negative_mask": self.negative_mask(x + v)}
             else:
                 yield {"user_id": users, "input_mask": d.dense("train_valid", users), "test_mask": d.dense("test", users)}
+        if self._flag is not None and int(self._flag.item()):
+            # a row asked for more negatives than it has non-positives: np.random.choice(replace=False)
+            # raises in the reference (cdae_dataset.py:27); here the check is one read per epoch
+            self._flag.zero_()
+            raise ValueError("Cannot take a larger sample than population when 'replace=False'")

@@ -469,6 +469,38 @@ def mf_recommend(U, I, users, mask_ptr, mask_idx, k, chunk_users=4096, fused=Non
     return out
 
 
+def csr_rows_to_dense(ptr, idx, users, num_items, out=None, accumulate=False, err_flag=None):
+    """[len(users), num_items] float32 0/1 rows from a per-user item CSR (device-side counterpart of
+    the dense masks of reference cdae_data_pipeline.py:33-37)."""
+    lib = _lib.load()
+    B = users.numel()
+    if out is None:
+        if accumulate:
+            raise EngineError("accumulate needs an output buffer")
+        out = torch.empty((B, num_items), dtype=torch.float32, device=users.device)
+    i64 = torch.int64
+    ii = idx if idx.numel() else torch.zeros(1, dtype=i64, device=users.device)
+    check(lib.yr_csr_rows_to_dense(_dev(ptr, i64, "ptr"), _dev(ii, i64, "idx"), _dev(users, i64, "users"), B,
+                                   ptr.numel() - 1, int(num_items), 1 if accumulate else 0,
+                                   _dev(out, torch.float32, "out"),
+                                   err_flag.data_ptr() if err_flag is not None else None, _stream()),
+          "yr_csr_rows_to_dense")
+    return out
+
+
+def negative_mask(positives, neg_times, seed, err_flag=None):
+    """Exactly ``neg_times * positives`` distinct non-positive items per row, uniformly at random
+    (reference cdae_dataset.py:20-34); ``err_flag`` gets FLAG_BAD_ITEM if a row has too few
+    non-positives (where np.random.choice raises)."""
+    lib = _lib.load()
+    B, I = positives.shape
+    out = torch.empty_like(positives)
+    check(lib.yr_negative_mask(_dev(positives, torch.float32, "positives"), B, I, int(neg_times),
+                               int(seed) & 0xFFFFFFFFFFFFFFFF, out.data_ptr(),
+                               err_flag.data_ptr() if err_flag is not None else None, _stream()), "yr_negative_mask")
+    return out
+
+
 def rank_metrics(topk, pos_ptr, pos_idx):
     """(precision, recall, map, ndcg)@k of reference metric.py computed on the device from the top-k
     lists ``topk [n, k]`` and the held-out items (CSR, original order).  Returns a float64[10] device
