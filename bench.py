@@ -63,13 +63,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # rehearsal hook for a one-GPU box: every rank on cuda:0 with gloo collectives (RCCL needs one
+    # device per rank); the driver's multi-GPU runs never set it
+    rehearsal = os.environ.get("YR_BENCH_REHEARSAL_ONE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)      # RCCL over xGMI
 
     from yelprecommendation_amd.bpr_step import BPRMFStep
     from yelprecommendation_amd.data.synthetic import YELP2018_ITEMS, YELP2018_USERS, make_interactions_torch
