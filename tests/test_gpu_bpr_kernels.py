@@ -265,3 +265,39 @@ def test_fused_eval_mask_value_paths_agree(device):
     np.testing.assert_array_equal(a, b)
     for r in range(0, n, 9):
         assert set(a[r, :4].tolist()) == set(range(ni)) - set(lists[r].tolist())
+
+
+def test_full_catalogue_eval_properties(device):
+    """BASELINE configs[1] catalogue size (38,048 items, D = 64): the fused kernel (sliced: few user
+    rows) against the unfused GEMM + top-k path on 2,000 users — same lists except at float near-ties,
+    masked items never recommended, lists sorted by score — and the device metrics of those lists
+    against the host definition."""
+    from yelprecommendation_amd import engine, metric
+    g = torch.Generator(device=device).manual_seed(0)
+    nu, ni, d, n, k = 31668, 38048, 64, 2000, 10
+    U = torch.randn(nu, d, device=device, generator=g) * 0.1
+    I = torch.randn(ni, d, device=device, generator=g) * 0.1
+    users = torch.randperm(nu, device=device, generator=g)[:n]
+    cnt = torch.randint(0, 60, (n,), device=device, generator=g)
+    ptr = torch.zeros(n + 1, dtype=torch.int64, device=device); ptr[1:] = torch.cumsum(cnt, 0)
+    idx = torch.randint(0, ni, (int(ptr[-1]),), device=device, generator=g)
+    fused = engine.mf_recommend(U, I, users, ptr, idx, k, fused=True)
+    plain = engine.mf_recommend(U, I, users, ptr, idx, k, fused=False)
+    assert (fused == plain).all(1).float().mean().item() >= 0.999
+    scores = (U[users] @ I.t())
+    picked = scores.gather(1, fused)
+    assert bool((picked[:, :-1] >= picked[:, 1:]).all())                      # descending
+    rows = torch.repeat_interleave(torch.arange(n, device=device), cnt)
+    hit = torch.zeros(n, ni, dtype=torch.bool, device=device); hit[rows, idx] = True
+    assert not bool(hit.gather(1, fused).any())                                # never a masked item
+    # every recommended score beats every unmasked, unrecommended score of its row
+    rest = scores.masked_fill(hit, float("-inf")).scatter(1, fused, float("-inf"))
+    assert bool((picked[:, -1] >= rest.max(1).values - 1e-6).all())
+    # metrics of these lists: device vs host definition
+    pos_cnt = torch.randint(0, 30, (n,), device=device, generator=g)
+    pptr = torch.zeros(n + 1, dtype=torch.int64, device=device); pptr[1:] = torch.cumsum(pos_cnt, 0)
+    pidx = torch.randint(0, ni, (int(pptr[-1]),), device=device, generator=g)
+    got = engine.rank_metrics(fused, pptr, pidx)[:4].cpu().numpy()
+    pp, pi = pptr.cpu().numpy(), pidx.cpu().numpy()
+    actual = [pi[pp[r]:pp[r + 1]].tolist() for r in range(n)]
+    np.testing.assert_allclose(got, metric.ranking_metrics(actual, fused.cpu().numpy().tolist(), k), rtol=1e-12)

@@ -276,3 +276,28 @@ def test_layer_sum_scores_flag_bad_ids(device):
     assert touched == [0, nu + 0, nu + 1]                    # only the valid triplet (0, 1, 0) scatters
     with pytest.raises(engine.EngineError):
         engine.ngcf_score([T[0]] * 9, nu, u, p, n)
+
+
+def test_full_size_spmm_properties(device):
+    """BASELINE configs[3] graph size (69,716 nodes, ~3.1 M non-zeros, D = 64): the SpMM is linear,
+    symmetric (<x, L y> == <L x, y>: L = D^-1/2 A D^-1/2), agrees with torch.sparse.mm, and
+    accumulate adds."""
+    from yelprecommendation_amd import engine
+    from yelprecommendation_amd.data.synthetic import YELP2018_ITEMS as NI, YELP2018_USERS as NU, make_interactions_torch
+    from yelprecommendation_amd.graph import LaplacianCSR
+    u, i = make_interactions_torch(NU, NI, 47.0, device=device)
+    r = torch.randint(1, 6, u.shape, device=device)
+    graph = LaplacianCSR.from_interactions(u.cpu().numpy(), i.cpu().numpy(), r.cpu().numpy(), NU, NI, device)
+    assert graph.n == NU + NI and graph.symmetric and graph.nnz > 3_000_000
+    g = torch.Generator(device=device).manual_seed(1)
+    x = torch.randn(graph.n, 64, device=device, generator=g)
+    y = torch.randn(graph.n, 64, device=device, generator=g)
+    Lx, Ly = engine.spmm_csr(graph, x), engine.spmm_csr(graph, y)
+    torch.testing.assert_close(engine.spmm_csr(graph, 2.0 * x - 3.0 * y), 2.0 * Lx - 3.0 * Ly, rtol=1e-4, atol=1e-4)
+    a, b = (x.double() * Ly.double()).sum().item(), (Lx.double() * y.double()).sum().item()
+    assert abs(a - b) <= 1e-5 * max(abs(a), abs(b), 1.0)
+    ref = torch.sparse.mm(graph.to_torch_sparse().to(device), x)
+    torch.testing.assert_close(Lx, ref, rtol=1e-4, atol=1e-5)
+    acc = y.clone()
+    engine.spmm_csr(graph, x, out=acc, accumulate=True)
+    torch.testing.assert_close(acc, y + Lx, rtol=1e-5, atol=1e-5)
