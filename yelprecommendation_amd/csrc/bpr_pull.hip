@@ -97,16 +97,23 @@ __device__ __forceinline__ int load_tile(Tile& t, const int64_t* __restrict__ us
   return bad;
 }
 
-// LDS histogram of the tile per bucket: s_cnt[0..nbU) users, s_cnt[nbU..nbU+nbI) items
-__device__ __forceinline__ void tile_histogram(const Tile& t, int32_t* s_cnt, int nbU, int nb_all) {
-  for (int i = threadIdx.x; i < nb_all; i += kPartThreads) s_cnt[i] = 0;
+// LDS histogram of the tile per bucket: s_cnt[0..nbU) users, s_cnt[nbU..nbU+nbI) items.
+// The partition kernels run TWO workgroups per tile (blockIdx.y = side): side 0 handles the user-side
+// buckets and records, side 1 the item-side ones — a tile of 8192 triplets per workgroup alone gives
+// only B / 8192 workgroups (128 at B = 2^20: half the CUs idle).
+__device__ __forceinline__ void tile_histogram(const Tile& t, int32_t* s_cnt, int nbU, int nb_all, int side) {
+  const int lo = side ? nbU : 0, hi = side ? nb_all : nbU;
+  for (int i = lo + threadIdx.x; i < hi; i += kPartThreads) s_cnt[i] = 0;
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < kPartPerThread; ++k) {
     if (t.u[k] >= 0) {
-      atomicAdd(&s_cnt[t.u[k] >> kBucketShift], 1);
-      atomicAdd(&s_cnt[nbU + (t.p[k] >> kBucketShift)], 1);
-      atomicAdd(&s_cnt[nbU + (t.n[k] >> kBucketShift)], 1);
+      if (side == 0) {
+        atomicAdd(&s_cnt[t.u[k] >> kBucketShift], 1);
+      } else {
+        atomicAdd(&s_cnt[nbU + (t.p[k] >> kBucketShift)], 1);
+        atomicAdd(&s_cnt[nbU + (t.n[k] >> kBucketShift)], 1);
+      }
     }
   }
   __syncthreads();
@@ -122,15 +129,17 @@ __global__ __launch_bounds__(kPartThreads) void part_count_kernel(const int64_t*
                                                                   int32_t* __restrict__ err_flag) {
   extern __shared__ int32_t s_cnt[];
   Tile t;
+  const int side = blockIdx.y;
   const int bad = load_tile(t, user, pos, neg, B, nU, nI);
-  tile_histogram(t, s_cnt, nbU, nb_all);
+  tile_histogram(t, s_cnt, nbU, nb_all, side);
   int32_t* mine = cnt_tile + (int64_t)blockIdx.x * nb_all;     // this tile's counts, reused by the scatter pass
-  for (int i = threadIdx.x; i < nb_all; i += kPartThreads) {
+  const int lo = side ? nbU : 0, hi = side ? nb_all : nbU;
+  for (int i = lo + threadIdx.x; i < hi; i += kPartThreads) {
     const int c = s_cnt[i];
     mine[i] = c;
     if (c) atomicAdd(&cnt_all[i], c);
   }
-  if (bad && err_flag) atomicOr(err_flag, bad);
+  if (side == 0 && bad && err_flag) atomicOr(err_flag, bad);
 }
 
 // exclusive scans of the user-bucket and item-bucket totals (block 0 / block 1):
@@ -188,7 +197,9 @@ __global__ __launch_bounds__(kPartThreads) void part_scatter_kernel(const int64_
   Tile t;
   load_tile(t, user, pos, neg, B, nU, nI);
   const int32_t* mine = cnt_tile + (int64_t)blockIdx.x * nb_all;   // counted by part_count_kernel
-  for (int i = threadIdx.x; i < nb_all; i += kPartThreads) {
+  const int side = blockIdx.y;                                     // 0: user-side records, 1: item-side
+  const int lo = side ? nbU : 0, hi = side ? nb_all : nbU;
+  for (int i = lo + threadIdx.x; i < hi; i += kPartThreads) {
     const int c = mine[i];
     s_start[i] = c ? atomicAdd(&cur_all[i], c) : 0;
     s_cnt[i] = 0;
@@ -197,15 +208,18 @@ __global__ __launch_bounds__(kPartThreads) void part_scatter_kernel(const int64_
 #pragma unroll
   for (int k = 0; k < kPartPerThread; ++k) {
     if (t.u[k] >= 0) {
-      const int bu = t.u[k] >> kBucketShift;
-      const int bp = nbU + (t.p[k] >> kBucketShift), bn = nbU + (t.n[k] >> kBucketShift);
-      const int su = s_start[bu] + atomicAdd(&s_cnt[bu], 1);
-      const int sp = s_start[bp] + atomicAdd(&s_cnt[bp], 1);
-      const int sn = s_start[bn] + atomicAdd(&s_cnt[bn], 1);
       const int b = (int)(blockIdx.x * kPartTile + threadIdx.x + k * kPartThreads);   // triplet id
-      user_rec[su] = make_int4(t.p[k], t.n[k] | ((t.u[k] & (kBucketRows - 1)) << kLocalShift), b, 0);
-      occ_rec[sp] = make_int2(t.u[k] | ((t.p[k] & (kBucketRows - 1)) << kLocalShift), b);
-      occ_rec[sn] = make_int2(t.u[k] | ((t.n[k] & (kBucketRows - 1)) << kLocalShift), b | (int)0x80000000);
+      if (side == 0) {
+        const int bu = t.u[k] >> kBucketShift;
+        const int su = s_start[bu] + atomicAdd(&s_cnt[bu], 1);
+        user_rec[su] = make_int4(t.p[k], t.n[k] | ((t.u[k] & (kBucketRows - 1)) << kLocalShift), b, 0);
+      } else {
+        const int bp = nbU + (t.p[k] >> kBucketShift), bn = nbU + (t.n[k] >> kBucketShift);
+        const int sp = s_start[bp] + atomicAdd(&s_cnt[bp], 1);
+        const int sn = s_start[bn] + atomicAdd(&s_cnt[bn], 1);
+        occ_rec[sp] = make_int2(t.u[k] | ((t.p[k] & (kBucketRows - 1)) << kLocalShift), b);
+        occ_rec[sn] = make_int2(t.u[k] | ((t.n[k] & (kBucketRows - 1)) << kLocalShift), b | (int)0x80000000);
+      }
     }
   }
 }
@@ -600,12 +614,12 @@ static int pull_index_impl(const int64_t* user, const int64_t* pos, const int64_
   if (e != hipSuccess) return (int)e;
   const int ptiles = (int)((B + kPartTile - 1) / kPartTile);
   if (ptiles > 0)
-    hipLaunchKernelGGL(part_count_kernel, dim3(ptiles), dim3(kPartThreads), (size_t)nb_all * 4, s, user, pos, neg, B,
+    hipLaunchKernelGGL(part_count_kernel, dim3(ptiles, 2), dim3(kPartThreads), (size_t)nb_all * 4, s, user, pos, neg, B,
                        nU, nI, w.nbU, nb_all, w.cnt_all, w.cnt_tile, err_flag);
   hipLaunchKernelGGL(part_scan_kernel, dim3(2), dim3(kPartThreads), 0, s, w.cnt_all, w.nbU, w.nbI, w.baseU, w.baseI,
                      w.cur_all);
   if (ptiles > 0)
-    hipLaunchKernelGGL(part_scatter_kernel, dim3(ptiles), dim3(kPartThreads), (size_t)nb_all * 8, s, user, pos, neg,
+    hipLaunchKernelGGL(part_scatter_kernel, dim3(ptiles, 2), dim3(kPartThreads), (size_t)nb_all * 8, s, user, pos, neg,
                        B, nU, nI, w.nbU, nb_all, w.cur_all, w.cnt_tile, w.rec1, w.occ1);
   // level-2 sort inside every bucket -> row offsets, records in row order, heavy lists
   SortSide su, si;
