@@ -159,3 +159,40 @@ def test_device_metrics_match_reference_definition(device, golden_dir):
         want = metric.ranking_metrics(actual, predicted.tolist(), k)
         np.testing.assert_allclose(out[:4], want, rtol=1e-12)
         assert out[4] == 3
+
+
+def test_checkpoint_resume_continues_the_run(g, tmp_path, device):
+    """save_checkpoint / load_checkpoint (weights + Adam moments + step counts): a fresh trainer that
+    loads the file and replays the next epoch's batches ends with the same tables as the trainer
+    that kept running — through the fused step (which shares the optimizer's state).  Equal to float
+    rounding, not bitwise: the scatter-add order of a step is not fixed."""
+    from yelprecommendation_amd.trainers import MFTrainer
+    cfg = _cfg(g, tmp_path)
+    rs = np.random.RandomState(4)
+    nu, ni = int(g["num_users"]), int(g["num_items"])
+    def batches(k):
+        return [{"user_id": torch.from_numpy(rs.randint(0, nu, 300)), "pos_item": torch.from_numpy(rs.randint(0, ni, 300)),
+                 "neg_item": torch.from_numpy(rs.randint(0, ni, 300))} for _ in range(k)]
+    first, second = batches(5), batches(5)
+    a = MFTrainer(cfg, ni, nu)
+    a.train(first)
+    path = os.path.join(str(tmp_path), "ckpt.pt")
+    a.save_checkpoint(path, epoch=1, best=0.25)
+    la = a.train(second)
+    b = MFTrainer(cfg, ni, nu)                                   # different random init, overwritten by the load
+    extra = b.load_checkpoint(path)
+    assert extra == {"epoch": 1, "best": 0.25}
+    lb = b.train(second)
+    assert abs(la - lb) <= 1e-6 * abs(la)
+    for (na, pa), (nb, pb) in zip(a.model.named_parameters(), b.model.named_parameters()):
+        assert na == nb
+        torch.testing.assert_close(pa, pb, rtol=1e-5, atol=1e-7)
+    sa, sb = a.optimizer.state_dict()["state"], b.optimizer.state_dict()["state"]
+    for k in sa:
+        assert sa[k]["step"] == sb[k]["step"] == 10
+        torch.testing.assert_close(sa[k]["exp_avg"], sb[k]["exp_avg"], rtol=1e-4, atol=1e-9)
+        torch.testing.assert_close(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"], rtol=1e-4, atol=1e-12)
+    # without the optimizer state the continuation is a different run
+    c = MFTrainer(cfg, ni, nu)
+    c.model.load_state_dict(a.model.state_dict())
+    assert c.optimizer.state_dict()["state"] == {}

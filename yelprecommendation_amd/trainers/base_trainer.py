@@ -112,6 +112,20 @@ class BaseTrainer(ABC):
     def evaluate(self, test_dataloader):
         pass
 
+    # -- resume (not in the reference, which saves weights only: SURVEY.md §8 f4) ---------------
+    def save_checkpoint(self, path, **extra):
+        """Weights (the reference's ``state_dict`` keys) + optimizer state (Adam moments and step
+        counts) + anything the caller wants to find again (epoch, best metric, ...)."""
+        torch.save({"model": self.model.state_dict(), "optimizer": self.optimizer.state_dict(), "extra": extra}, path)
+
+    def load_checkpoint(self, path):
+        """Restore what :meth:`save_checkpoint` wrote; training continues as if it had never stopped (to
+        float rounding) when fed the same batches.  Returns the ``extra`` dict."""
+        ck = torch.load(path, map_location=self.device, weights_only=True)
+        self.model.load_state_dict(ck["model"])
+        self.optimizer.load_state_dict(ck["optimizer"])
+        return ck.get("extra", {})
+
     def load_best_model(self):
         # reference base_trainer.py:155-157 (weights_only: the file holds tensors only)
         logger.info("[Trainer] Load best model...")
