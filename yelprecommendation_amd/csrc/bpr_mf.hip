@@ -357,6 +357,9 @@ __global__ __launch_bounds__(kBlock) void bpr_loss_fwd_kernel(const float* __res
     acc += softplus_neg(pos[b] - neg[b]);
   const float total = block_sum(acc, s_red);
   if (threadIdx.x == 0) partials[blockIdx.x] = total;
+  // the slots no workgroup owns are cleared by workgroup 0 (no second launch for the tail)
+  if (blockIdx.x == 0)
+    for (int i = gridDim.x + threadIdx.x; i < YR_LOSS_PARTIALS; i += kBlock) partials[i] = 0.0f;
 }
 
 // gpos[b] = -sigmoid(-(pos-neg)) * gout[0] * inv_batch ; gneg[b] = -gpos[b]
@@ -381,11 +384,11 @@ extern "C" int yr_bpr_loss_fwd(const float* pos, const float* neg, int64_t B, fl
   if (B > 0 && (!pos || !neg)) return YR_ERR_BADARG;
   hipStream_t s = (hipStream_t)stream;
   const int grid = B > 0 ? grid_for(B, kBlock) : 0;
-  if (grid) hipLaunchKernelGGL(bpr_loss_fwd_kernel, dim3(grid), dim3(kBlock), 0, s, pos, neg, B, loss_partials);
-  if (grid < YR_LOSS_PARTIALS) {
-    const int rest = YR_LOSS_PARTIALS - grid;
-    hipLaunchKernelGGL(clear_tail_kernel, dim3((rest + kBlock - 1) / kBlock), dim3(kBlock), 0, s, loss_partials,
-                       grid, YR_LOSS_PARTIALS);
+  if (grid) {
+    hipLaunchKernelGGL(bpr_loss_fwd_kernel, dim3(grid), dim3(kBlock), 0, s, pos, neg, B, loss_partials);
+  } else {
+    hipLaunchKernelGGL(clear_tail_kernel, dim3(YR_LOSS_PARTIALS / kBlock), dim3(kBlock), 0, s, loss_partials, 0,
+                       YR_LOSS_PARTIALS);
   }
   return launch_status();
 }
