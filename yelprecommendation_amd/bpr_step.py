@@ -162,7 +162,7 @@ class BPRMFStep:
         ws = self._workspace(B, slot)
         rc = self._lib.yr_bpr_mf_pull_index(u.data_ptr(), p.data_ptr(), n.data_ptr(), B, self.U.shape[0],
                                             self.I.shape[0], self.heavy_threshold, ws.data_ptr(), ws.numel(),
-                                            self._pflag, torch.cuda.current_stream().cuda_stream)
+                                            self._pflag, engine._stream())
         if rc:
             engine.check(rc, "yr_bpr_mf_pull_index")
         # keep the tensors alive (and identify the batch) until the index is consumed
@@ -195,7 +195,7 @@ class BPRMFStep:
                 step_size, bc2_sqrt, self.betas[0], self.betas[1], self.eps, self.wd,
                 engine.OPT_ADAMW if self.decoupled else engine.OPT_ADAM, self.heavy_threshold,
                 ws.data_ptr(), ws.numel(), self._ppartials, phases, r0, r1,
-                torch.cuda.current_stream().cuda_stream)
+                engine._stream())
             if rc:
                 engine.check(rc, "yr_bpr_mf_pull_apply")
 
@@ -238,7 +238,7 @@ class BPRMFStep:
         self._gI_dirty = multi
         self.U, self._U_alt = self._U_alt, self.U
         rc = self._lib.yr_loss_finalize(self._ppartials, inv, self.loss.data_ptr(), self.loss_accum.data_ptr(),
-                                        torch.cuda.current_stream().cuda_stream)
+                                        engine._stream())
         if rc:
             engine.check(rc, "yr_loss_finalize")
 
@@ -246,7 +246,7 @@ class BPRMFStep:
         B = self._check_triplets(u, p, n)
         D = self.U.shape[1]
         inv = 1.0 / global_batch if global_batch else 0.0
-        lib, stream = self._lib, torch.cuda.current_stream().cuda_stream
+        lib, stream = self._lib, engine._stream()
         if self._gI_dirty:                      # a pull-form multi-GPU step left the reduced gradient there
             self.gI.zero_()
             self._gI_dirty = False

@@ -18,7 +18,15 @@ PULL_USER_PHASE, PULL_ITEM_PHASE = 1, 2
 SUPPORTED_WIDTHS = (16, 32, 64, 128)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """hipStream_t of torch's current stream on the current device (follows torch.cuda.stream()).
+    The raw accessor costs 0.3 us per call against 2.7 us for current_stream().cuda_stream — it is on
+    every launch."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
