@@ -410,38 +410,59 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void ngcf_dense_bwd_weight_kernel(
     const float* __restrict__ dEout, const float* __restrict__ Eout, const float* __restrict__ E,
     const float* __restrict__ Z, int n, float* __restrict__ dW1, float* __restrict__ dW2) {
-  constexpr int PITCH = D + 1;
+  // pitch D: an MFMA operand read is 32 consecutive floats of one staged row per half-wave, which is
+  // conflict-free at any pitch, and a multiple of 4 keeps the staging stores 16 bytes wide
+  constexpr int PITCH = D;
   constexpr int kWRows = WChunk<D>::ROWS;
   constexpr int RT = (D + 31) / 32;          // tiles along j (rows of dW) and along c (per matrix)
   constexpr int NT = RT * RT * 2;            // output tiles: RT x RT for dW1, same for dW2
-  __shared__ float s_dp[kWRows * PITCH];
-  __shared__ float s_a[kWRows * PITCH];
-  __shared__ float s_h[kWRows * PITCH];
+  constexpr int NV = kWRows * D / 4 / kBlock;   // float4 per thread per operand and chunk (= 4)
+  __shared__ __attribute__((aligned(16))) float s_dp[kWRows * PITCH];
+  __shared__ __attribute__((aligned(16))) float s_a[kWRows * PITCH];
+  __shared__ __attribute__((aligned(16))) float s_h[kWRows * PITCH];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int i = lane & 31, h = lane >> 5;
   constexpr int TPW = (NT + kWavesPerBlock - 1) / kWavesPerBlock;   // output tiles per wave
   f32x16 acc[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) acc[t] = zero16();
+  // the next chunk's rows travel in registers while the MFMAs of the current chunk run
+  float4 pg[NV], po[NV], pe[NV], pz[NV];
+  auto fetch = [&](int64_t row0) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int q = threadIdx.x + v * kBlock;
+      const int64_t r = row0 + q / (D / 4);
+      const int c4 = (q % (D / 4)) * 4;
+      pg[v] = po[v] = pe[v] = pz[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < n) {
+        const int64_t o = r * D + c4;
+        pg[v] = ngcf_ld4(dEout + o); po[v] = ngcf_ld4(Eout + o); pe[v] = ngcf_ld4(E + o); pz[v] = ngcf_ld4(Z + o);
+      }
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int q = threadIdx.x + v * kBlock;
+      const int at = (q / (D / 4)) * PITCH + (q % (D / 4)) * 4;
+      const float4 g = pg[v], o = po[v], e = pe[v], z = pz[v];
+      *reinterpret_cast<float4*>(s_dp + at) = make_float4(o.x > 0.0f ? g.x : kSlope * g.x, o.y > 0.0f ? g.y : kSlope * g.y,
+                                                          o.z > 0.0f ? g.z : kSlope * g.z, o.w > 0.0f ? g.w : kSlope * g.w);
+      *reinterpret_cast<float4*>(s_a + at) = make_float4(z.x + e.x, z.y + e.y, z.z + e.z, z.w + e.w);
+      *reinterpret_cast<float4*>(s_h + at) = make_float4(e.x * z.x, e.y * z.y, e.z * z.z, e.w * z.w);
+    }
+  };
   // persistent over row chunks: the 2 D^2 partial sums stay in registers until the end, so the
   // float atomics on dW scale with the grid, not with n
-  for (int64_t row0 = (int64_t)blockIdx.x * kWRows; row0 < n; row0 += (int64_t)gridDim.x * kWRows) {
+  const int64_t stride = (int64_t)gridDim.x * kWRows;
+  int64_t row0 = (int64_t)blockIdx.x * kWRows;
+  if (row0 < n) fetch(row0);
+  for (; row0 < n; row0 += stride) {
+    __syncthreads();                                 // the previous chunk's MFMAs are done with the LDS tiles
+    stash();
     __syncthreads();
-    for (int q = threadIdx.x; q < kWRows * D; q += kBlock) {
-      const int r = q / D, c = q % D;
-      float dp = 0.f, av = 0.f, hv = 0.f;
-      if (row0 + r < n) {
-        const int64_t o = (int64_t)(row0 + r) * D + c;
-        const float g = dEout[o], eo = Eout[o], e = E[o], z = Z[o];
-        dp = eo > 0.0f ? g : kSlope * g;
-        av = z + e;
-        hv = e * z;
-      }
-      s_dp[r * PITCH + c] = dp;
-      s_a[r * PITCH + c] = av;
-      s_h[r * PITCH + c] = hv;
-    }
-    __syncthreads();
+    if (row0 + stride < n) fetch(row0 + stride);
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       const int tile = wave + t * kWavesPerBlock;
