@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 17
+#define YR_ENGINE_VERSION 18
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -283,11 +283,12 @@ int yr_mf_eval_topk(const float *U, const float *I, const int64_t *users, int64_
  * mask_value = -3.40282e+38 reproduces `pred[mask_items] = -3.40282e+38`; 0 reproduces
  * CDAE's `pred * logical_not(input_mask)`.  mask_ptr may be NULL (no mask).  k <= 64.
  * Rows shorter than k are padded with -1.  `scores` is not modified.
+ * mask_rows (may be NULL): row r's mask list is CSR row mask_rows[r] instead of r.
  * replaces: numpy fancy-index store + argpartition + take_along_axis + argsort per user.
  * ------------------------------------------------------------------------- */
 int yr_topk_masked(const float *scores, int64_t nrows, int64_t ncols, int64_t row_stride,
-                   const int64_t *mask_ptr, const int64_t *mask_idx, float mask_value,
-                   int k, int64_t *out, void *stream);
+                   const int64_t *mask_ptr, const int64_t *mask_idx, const int64_t *mask_rows,
+                   float mask_value, int k, int64_t *out, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Ranking metrics on the device      (reference metric.py:7-109, with its quirks: recall / MAP /
@@ -298,10 +299,12 @@ int yr_topk_masked(const float *scores, int64_t nrows, int64_t ncols, int64_t ro
  *   out (10 float64): [0..3] = precision@k, recall@k, MAP@k, NDCG@k, [4] = users with non-empty
  *   `actual`, [5..8] = the four un-normalised sums and [9] = n (a user-sharded evaluation sums
  *   [4..9] over ranks and divides once).  workspace: yr_rank_metrics_workspace_bytes(n) bytes.
+ *   pos_rows (may be NULL): row r's list is CSR row pos_rows[r] instead of r — a batch of users can
+ *   point into one per-user CSR that lives on the device (no per-batch CSR is built).
  * ------------------------------------------------------------------------- */
 int64_t yr_rank_metrics_workspace_bytes(int64_t n);
 int yr_rank_metrics(const int64_t *topk, int64_t n, int k, const int64_t *pos_ptr, const int64_t *pos_idx,
-                    double *workspace, double *out, void *stream);
+                    const int64_t *pos_rows, double *workspace, double *out, void *stream);
 
 /* ---------------------------------------------------------------------------
  * BPRLoss.forward / backward on score vectors        (reference loss.py:25-27)

@@ -286,3 +286,33 @@ def test_device_batches_match_host_definitions(device):
                                               device), "train", 4, neg_times=2)
     with pytest.raises(ValueError):
         list(loader)
+
+
+def test_user_indexed_item_lists_equal_mask_derived_lists(device, tmp_path, g):
+    """The CDAE trainer's metric sums through the loader's per-user CSR (yr_topk_masked / yr_rank_metrics
+    with row indirection) equal the ones derived from the dense masks with nonzero(), in valid and test
+    mode; and the plain kernels with an explicit row map equal the re-packed CSR."""
+    from yelprecommendation_amd import engine
+    from yelprecommendation_amd.data.cdae_batches import CDAEBatchLoader, CDAEInteractions
+    from yelprecommendation_amd.trainers import CDAETrainer
+    rs = np.random.RandomState(2)
+    nu, ni = 90, 700
+    u = np.repeat(np.arange(nu), 20); i = rs.randint(0, ni, size=u.shape[0])
+    data = CDAEInteractions.from_interactions(torch.from_numpy(u), torch.from_numpy(i), nu, ni, seed=1, device=device)
+    t = CDAETrainer(_cfg(g, tmp_path, negative_sampling=True), ni, nu)
+    for mode, key in (("valid", "valid_mask"), ("test", "test_mask")):
+        for batch in CDAEBatchLoader(data, mode, batch_size=32, neg_times=1, shuffle=True, seed=3):
+            pred = torch.rand(batch["user_id"].numel(), ni, device=device) + 0.01
+            a = t._metric_sums(pred, batch[key], batch["input_mask"], batch["item_lists"])
+            b = t._metric_sums(pred, batch[key], batch["input_mask"], None)
+            torch.testing.assert_close(a, b, rtol=1e-12, atol=0)
+    # row map on the raw kernels: rows listed twice / out of order
+    ptr, idx = data.csr("train")
+    rows = torch.tensor([5, 5, 0, 89, 17], device=device)
+    scores = torch.rand(5, ni, device=device)
+    got = engine.topk_masked(scores, ptr, idx, 10, mask_rows=rows)
+    cnt = (ptr[1:] - ptr[:-1])[rows]
+    p2 = torch.zeros(6, dtype=torch.int64, device=device); p2[1:] = torch.cumsum(cnt, 0)
+    i2 = torch.cat([idx[ptr[r]:ptr[r + 1]] for r in rows.tolist()])
+    assert torch.equal(got, engine.topk_masked(scores, p2, i2, 10))
+    torch.testing.assert_close(engine.rank_metrics(got, ptr, idx, pos_rows=rows), engine.rank_metrics(got, p2, i2), rtol=1e-12, atol=0)

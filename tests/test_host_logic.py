@@ -50,7 +50,7 @@ def test_argument_checks_without_gpu():
     assert 50e6 < n < 120e6                      # ~72 B per triplet + per-row tables
     assert lib.yr_adam_dense(None, None, None, None, 16, 1e-3, 1e-3, 1.0, 0.9, 0.999, 1e-8, 0.0, 0, 0, None) == -2
     assert lib.yr_adam_dense(None, None, None, None, 0, 1e-3, 1e-3, 1.0, 0.9, 0.999, 1e-8, 0.0, 0, 0, None) == 0
-    assert lib.yr_topk_masked(None, 1, 10, 10, None, None, 0.0, 100, None, None) == -2   # k > 64
+    assert lib.yr_topk_masked(None, 1, 10, 10, None, None, None, 0.0, 100, None, None) == -2   # k > 64
 
 
 def test_ops_refuse_cpu_tensors():

@@ -28,13 +28,15 @@ constexpr int kMetricBlock = kWave;   // one wave per workgroup: ~500 workgroups
 __global__ __launch_bounds__(kMetricBlock) void rank_metrics_kernel(const int64_t* __restrict__ topk, int64_t n, int k,
                                                               const int64_t* __restrict__ pos_ptr,
                                                               const int64_t* __restrict__ pos_idx,
+                                                              const int64_t* __restrict__ pos_rows,
                                                               double* __restrict__ partial) {
   double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   const int64_t u = (int64_t)blockIdx.x * kMetricBlock + threadIdx.x;
   if (u < n) {
     const int64_t* pred = topk + u * k;
-    const int64_t* act = pos_idx + pos_ptr[u];
-    const int len = (int)(pos_ptr[u + 1] - pos_ptr[u]);
+    const int64_t pr = pos_rows ? pos_rows[u] : u;               // which CSR row holds this user's list
+    const int64_t* act = pos_idx + pos_ptr[pr];
+    const int len = (int)(pos_ptr[pr + 1] - pos_ptr[pr]);
     // hits = |set(actual) & set(pred[:k])| : distinct predicted items that occur in actual
     int hits = 0;
     for (int i = 0; i < k; ++i) {
@@ -115,13 +117,13 @@ extern "C" int64_t yr_rank_metrics_workspace_bytes(int64_t n) {
 }
 
 extern "C" int yr_rank_metrics(const int64_t* topk, int64_t n, int k, const int64_t* pos_ptr, const int64_t* pos_idx,
-                               double* workspace, double* out, void* stream) {
+                               const int64_t* pos_rows, double* workspace, double* out, void* stream) {
   if (n <= 0 || k <= 0) return YR_ERR_BADARG;
   if (!topk || !pos_ptr || !workspace || !out) return YR_ERR_BADARG;
   const int nblocks = (int)((n + kMetricBlock - 1) / kMetricBlock);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(rank_metrics_kernel, dim3(nblocks), dim3(kMetricBlock), 0, s, topk, n, k, pos_ptr, pos_idx,
-                     workspace);
+                     pos_rows, workspace);
   hipLaunchKernelGGL(rank_metrics_finalize_kernel, dim3(1), dim3(kWave), 0, s, workspace, nblocks, n, out);
   return launch_status();
 }

@@ -29,7 +29,8 @@ template <int K>
 __global__ __launch_bounds__(kBlock) void topk_masked_kernel(const float* __restrict__ scores, int64_t ncols,
                                                              int64_t row_stride,
                                                              const int64_t* __restrict__ mask_ptr,
-                                                             const int64_t* __restrict__ mask_idx, float mask_value,
+                                                             const int64_t* __restrict__ mask_idx,
+                                                             const int64_t* __restrict__ mask_rows, float mask_value,
                                                              int k, int64_t* __restrict__ out) {
   extern __shared__ uint32_t s_bits[];                 // ceil(ncols / 32) words
   __shared__ float s_ws[kWavesPerBlock];
@@ -42,7 +43,8 @@ __global__ __launch_bounds__(kBlock) void topk_masked_kernel(const float* __rest
   for (int w = threadIdx.x; w < nwords; w += kBlock) s_bits[w] = 0u;
   __syncthreads();
   if (mask_ptr) {
-    const int64_t lo = mask_ptr[row], hi = mask_ptr[row + 1];
+    const int64_t mr = mask_rows ? mask_rows[row] : row;          // which CSR row holds this row's mask list
+    const int64_t lo = mask_ptr[mr], hi = mask_ptr[mr + 1];
     for (int64_t q = lo + threadIdx.x; q < hi; q += kBlock) {
       const int64_t c = mask_idx[q];
       if ((uint64_t)c < (uint64_t)ncols) atomicOr(&s_bits[c >> 5], 1u << (c & 31));
@@ -115,8 +117,8 @@ __global__ __launch_bounds__(kBlock) void topk_masked_kernel(const float* __rest
 using namespace yr;
 
 extern "C" int yr_topk_masked(const float* scores, int64_t nrows, int64_t ncols, int64_t row_stride,
-                              const int64_t* mask_ptr, const int64_t* mask_idx, float mask_value, int k,
-                              int64_t* out, void* stream) {
+                              const int64_t* mask_ptr, const int64_t* mask_idx, const int64_t* mask_rows,
+                              float mask_value, int k, int64_t* out, void* stream) {
   if (nrows < 0 || ncols <= 0 || k <= 0 || k > 64 || row_stride < ncols) return YR_ERR_BADARG;
   if (ncols > (int64_t)1 << 20) return YR_ERR_UNSUPPORTED;          // LDS bitmap: 128 KiB at 2^20 columns
   if (nrows == 0) return 0;
@@ -126,12 +128,12 @@ extern "C" int yr_topk_masked(const float* scores, int64_t nrows, int64_t ncols,
   // per-thread list size = next of {16, 32, 64} holding k
   if (k <= 16)
     hipLaunchKernelGGL((topk_masked_kernel<16>), dim3((unsigned)nrows), dim3(kBlock), lds, s, scores, ncols,
-                       row_stride, mask_ptr, mask_idx, mask_value, k, out);
+                       row_stride, mask_ptr, mask_idx, mask_rows, mask_value, k, out);
   else if (k <= 32)
     hipLaunchKernelGGL((topk_masked_kernel<32>), dim3((unsigned)nrows), dim3(kBlock), lds, s, scores, ncols,
-                       row_stride, mask_ptr, mask_idx, mask_value, k, out);
+                       row_stride, mask_ptr, mask_idx, mask_rows, mask_value, k, out);
   else
     hipLaunchKernelGGL((topk_masked_kernel<64>), dim3((unsigned)nrows), dim3(kBlock), lds, s, scores, ncols,
-                       row_stride, mask_ptr, mask_idx, mask_value, k, out);
+                       row_stride, mask_ptr, mask_idx, mask_rows, mask_value, k, out);
   return launch_status();
 }

@@ -88,6 +88,18 @@ class CDAEInteractions:
         return cls(num_users, num_items, parts, device)
 
     # -- access -------------------------------------------------------------------------------
+    def csr(self, part):
+        """(ptr, idx) of ``part``; 'train_valid' (train | valid per user, ids ascending) is merged on
+        first use."""
+        if part == "train_valid" and part not in self._csr:
+            pt, it = self._csr["train"]
+            pv, iv = self._csr["valid"]
+            users = torch.arange(self.num_users, device=self.device)
+            rows = torch.cat([torch.repeat_interleave(users, pt[1:] - pt[:-1]),
+                              torch.repeat_interleave(users, pv[1:] - pv[:-1])])
+            self._csr[part] = _csr_from_pairs(rows, torch.cat([it, iv]), self.num_users)
+        return self._csr[part]
+
     def counts(self, part):
         ptr, _ = self._csr[part]
         return ptr[1:] - ptr[:-1]
@@ -160,14 +172,23 @@ class CDAEBatchLoader:
                  else torch.arange(d.num_users, device=d.device))
         for s in range(0, d.num_users, self.batch_size):
             users = order[s:s + self.batch_size]
+            # beside the reference's keys: where the held-out and the seen items of these users live
+            # in the per-user CSR, so that evaluation needs no nonzero() over the dense masks
+            lists = {"users": users}
+            if self.mode == "valid":
+                lists.update(actual=d.csr("valid"), seen=d.csr("train"))
+            elif self.mode == "test":
+                lists.update(actual=d.csr("test"), seen=d.csr("train_valid"))
             if self.mode == "train":
                 x = d.dense("train", users)
                 yield {"user_id": users, "input_mask": x, "negative_mask": self.negative_mask(x)}
             elif self.mode == "valid":
                 x, v = d.dense("train", users), d.dense("valid", users)
-                yield {"user_id": users, "input_mask": x, "valid_mask": v, "negative_mask": self.negative_mask(x + v)}
+                yield {"user_id": users, "input_mask": x, "valid_mask": v, "negative_mask": self.negative_mask(x + v),
+                       "item_lists": lists}
             else:
-                yield {"user_id": users, "input_mask": d.dense("train_valid", users), "test_mask": d.dense("test", users)}
+                yield {"user_id": users, "input_mask": d.dense("train_valid", users), "test_mask": d.dense("test", users),
+                       "item_lists": lists}
         if self._flag is not None and int(self._flag.item()):
             # a row asked for more negatives than it has non-positives: np.random.choice(replace=False)
             # raises in the reference (cdae_dataset.py:27); here the check is one read per epoch

@@ -380,9 +380,11 @@ def loss_finalize(loss_partials, scale, loss_out=None, loss_accum=None):
 MASK_VALUE = -3.40282e+38     # reference trainers/mf_trainer.py:167
 
 
-def topk_masked(scores, mask_ptr, mask_idx, k, mask_value=MASK_VALUE, out=None):
+def topk_masked(scores, mask_ptr, mask_idx, k, mask_value=MASK_VALUE, out=None, mask_rows=None):
     """Row-wise top-k of ``scores[R, N]`` with per-row masked columns (CSR) forced to
-    ``mask_value`` first (reference trainers/mf_trainer.py:163-178).  -> int64 [R, k]."""
+    ``mask_value`` first (reference trainers/mf_trainer.py:163-178).  -> int64 [R, k].
+    ``mask_rows`` [R]: row r's mask list is CSR row ``mask_rows[r]`` (a batch of users pointing into one
+    per-user CSR) instead of row r."""
     lib = _lib.load()
     if scores.dim() != 2 or scores.stride(1) != 1:
         raise EngineError("scores must be [rows, cols] with unit column stride")
@@ -391,10 +393,13 @@ def topk_masked(scores, mask_ptr, mask_idx, k, mask_value=MASK_VALUE, out=None):
     R, N = scores.shape
     if out is None:
         out = torch.empty((R, k), dtype=torch.int64, device=scores.device)
-    if mask_ptr is not None and mask_ptr.numel() != R + 1:
+    if mask_ptr is not None and mask_rows is None and mask_ptr.numel() != R + 1:
         raise EngineError("mask_ptr must have rows + 1 entries")
+    if mask_rows is not None and mask_rows.numel() != R:
+        raise EngineError("mask_rows must have one entry per row")
     check(lib.yr_topk_masked(scores.data_ptr(), R, N, scores.stride(0) if R > 1 else N,
                              _opt(mask_ptr, torch.int64, "mask_ptr"), _opt(mask_idx, torch.int64, "mask_idx"),
+                             _opt(mask_rows, torch.int64, "mask_rows"),
                              float(mask_value), int(k), _dev(out, torch.int64, "out"), _stream()),
           "yr_topk_masked")
     return out
@@ -509,20 +514,23 @@ def negative_mask(positives, neg_times, seed, err_flag=None):
     return out
 
 
-def rank_metrics(topk, pos_ptr, pos_idx):
+def rank_metrics(topk, pos_ptr, pos_idx, pos_rows=None):
     """(precision, recall, map, ndcg)@k of reference metric.py computed on the device from the top-k
     lists ``topk [n, k]`` and the held-out items (CSR, original order).  Returns a float64[10] device
     tensor: the four metrics, the number of users with a non-empty list, then the four un-normalised
     sums and n (for a cross-rank reduction); one host sync to read it."""
     lib = _lib.load()
     n, k = topk.shape
-    if pos_ptr.numel() != n + 1:
+    if pos_rows is None and pos_ptr.numel() != n + 1:
         raise EngineError("pos_ptr must have rows + 1 entries")
+    if pos_rows is not None and pos_rows.numel() != n:
+        raise EngineError("pos_rows must have one entry per row")
     ws = torch.empty(lib.yr_rank_metrics_workspace_bytes(n) // 8, dtype=torch.float64, device=topk.device)
     out = torch.empty(10, dtype=torch.float64, device=topk.device)
     idx = pos_idx if pos_idx.numel() else torch.zeros(1, dtype=torch.int64, device=topk.device)
     check(lib.yr_rank_metrics(_dev(topk, torch.int64, "topk"), n, k, _dev(pos_ptr, torch.int64, "pos_ptr"),
-                              _dev(idx, torch.int64, "pos_idx"), ws.data_ptr(), out.data_ptr(), _stream()),
+                              _dev(idx, torch.int64, "pos_idx"), _opt(pos_rows, torch.int64, "pos_rows"),
+                              ws.data_ptr(), out.data_ptr(), _stream()),
           "yr_rank_metrics")
     return out
 

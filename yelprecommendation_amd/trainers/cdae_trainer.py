@@ -87,7 +87,7 @@ class CDAETrainer(BaseTrainer):
                     actual.extend(batch_actual)
                     predicted.extend(batch_predicted)
                 else:
-                    sums += self._metric_sums(pred, valid_mask, input_mask)
+                    sums += self._metric_sums(pred, valid_mask, input_mask, data.get('item_lists'))
         p, r, m, n = self._metrics(host, actual, predicted, sums)
         return (float(self._loss_accum.item()), p, r, m, n)
 
@@ -108,7 +108,7 @@ class CDAETrainer(BaseTrainer):
                     actual.extend(batch_actual)
                     predicted.extend(batch_predicted)
                 else:
-                    sums += self._metric_sums(pred, test_mask, input_mask)
+                    sums += self._metric_sums(pred, test_mask, input_mask, data.get('item_lists'))
         p, r, m, n = self._metrics(host, actual, predicted, sums)
         logger.info(f"[Trainer] Test > precision@{self.cfg.top_n} : {p:.4f} / Recall@{self.cfg.top_n}: {r:.4f} / "
                     f"MAP@{self.cfg.top_n}: {m:.4f} / NDCG@{self.cfg.top_n}: {n:.4f}")
@@ -129,8 +129,16 @@ class CDAETrainer(BaseTrainer):
         ptr[1:] = torch.cumsum(torch.bincount(nz[:, 0], minlength=mask.shape[0]), 0)
         return ptr, nz[:, 1].contiguous()
 
-    def _metric_sums(self, pred, actual_mask, pred_mask):
-        """[users with held-out items, precision / recall / AP / NDCG sums, users] of one batch."""
+    def _metric_sums(self, pred, actual_mask, pred_mask, item_lists=None):
+        """[users with held-out items, precision / recall / AP / NDCG sums, users] of one batch.
+        ``item_lists`` (from data/cdae_batches.py): the batch's users plus the per-user CSR of their
+        seen and held-out items already on the device — the kernels index it by user, nothing is
+        derived from the dense masks."""
+        if item_lists is not None:
+            users = item_lists["users"].contiguous()
+            (sp, si), (ap, ai) = item_lists["seen"], item_lists["actual"]
+            top = engine.topk_masked(pred.detach().contiguous(), sp, si, self.cfg.top_n, mask_value=0.0, mask_rows=users)
+            return engine.rank_metrics(top, ap, ai, pos_rows=users)[4:10]
         mask_ptr, mask_idx = self._rows_to_csr(pred_mask)
         top = engine.topk_masked(pred.detach().contiguous(), mask_ptr, mask_idx, self.cfg.top_n, mask_value=0.0)
         pos_ptr, pos_idx = self._rows_to_csr(actual_mask)
