@@ -7,15 +7,17 @@
 //                          subset equally likely — np.random.choice(non-positives, k, replace=False)
 //                          of cdae_dataset.py:20-34.  Each non-positive item gets an i.i.d. 64-bit
 //                          Philox key (regenerated from (seed, row, item) whenever needed, never
-//                          stored); the k smallest keys win; the k-th smallest key is found by an
-//                          11-bit-per-pass radix select over LDS histograms.
+//                          stored); the k smallest keys win.  The k-th smallest key: one LDS
+//                          histogram of the top 11 key bits, then the few keys of the bin that
+//                          holds it are ranked in LDS (11 more bits per pass only for rows so long
+//                          that a bin overflows the list).
 #include "common.h"
 
 namespace yr {
 
 __device__ __forceinline__ uint4 cb_philox(uint4 ctr, uint2 key) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < 7; ++r) {                        // Philox4x32-7 (the shortest variant that passes BigCrush)
     const uint32_t hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
     const uint32_t hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
     ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
@@ -57,28 +59,42 @@ __global__ __launch_bounds__(kBlock) void csr_rows_to_dense_kernel(const int64_t
 constexpr int kNmDigitBits = 11;
 constexpr int kNmBins = 1 << kNmDigitBits;
 
-// one workgroup per row
-__global__ __launch_bounds__(kBlock) void negative_mask_kernel(const float* __restrict__ pos, int64_t num_items,
+constexpr int kNmListCap = 512;                       // keys of the selected top-digit bin kept in LDS
+
+// one workgroup of kNmThreads per row: 16 waves on the CU that owns the row (with 256 threads the
+// kernel ran one wave per SIMD and every pass was a chain of exposed memory latencies)
+constexpr int kNmThreads = 1024;
+constexpr int kNmWaves = kNmThreads / kWave;
+
+__global__ __launch_bounds__(kNmThreads) void negative_mask_kernel(const float* __restrict__ pos, int64_t num_items,
                                                                int neg_times, uint64_t seed, float* __restrict__ out,
                                                                int32_t* __restrict__ err_flag) {
   __shared__ int s_hist[kNmBins];
-  __shared__ int s_red[kWavesPerBlock];
-  __shared__ int s_sel_digit, s_sel_before, s_sel_count;
+  __shared__ int s_red[kNmWaves];
+  __shared__ unsigned long long s_keys[kNmListCap];
+  __shared__ int s_sel_digit, s_sel_before, s_sel_count, s_nkeys;
+  __shared__ unsigned long long s_thr;
   const int64_t row = blockIdx.x;
   const float* p = pos + row * num_items;
   float* o = out + row * num_items;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
 
-  // positives of the row
+  // pass 1: positives of the row, and the histogram of the top 11 key bits of the non-positives
+  for (int b = threadIdx.x; b < kNmBins; b += kNmThreads) s_hist[b] = 0;
+  if (threadIdx.x == 0) s_nkeys = 0;
+  __syncthreads();
   int cnt = 0;
-  for (int64_t c = threadIdx.x; c < num_items; c += kBlock) cnt += p[c] > 0.0f;
+  for (int64_t c = threadIdx.x; c < num_items; c += kNmThreads) {
+    if (p[c] > 0.0f) { ++cnt; continue; }
+    atomicAdd(&s_hist[(int)(cb_key(seed, row, c) >> (64 - kNmDigitBits))], 1);
+  }
 #pragma unroll
   for (int m = kWave / 2; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, kWave);
   if (lane == 0) s_red[wave] = cnt;
   __syncthreads();
   int positives = 0;
 #pragma unroll
-  for (int w = 0; w < kWavesPerBlock; ++w) positives += s_red[w];
+  for (int w = 0; w < kNmWaves; ++w) positives += s_red[w];
   int64_t need = (int64_t)neg_times * positives;
   const int64_t room = num_items - positives;
   if (need > room) {                                   // np.random.choice(replace=False) raises; flagged for the host
@@ -86,60 +102,89 @@ __global__ __launch_bounds__(kBlock) void negative_mask_kernel(const float* __re
     need = room;
   }
   if (need <= 0) {
-    for (int64_t c = threadIdx.x; c < num_items; c += kBlock) o[c] = 0.0f;
+    for (int64_t c = threadIdx.x; c < num_items; c += kNmThreads) o[c] = 0.0f;
     return;
   }
 
-  // radix select of the need-th smallest key among the non-positives
-  uint64_t prefix = 0;                                 // the digits fixed so far (top bits_done bits of the key)
-  int bits_done = 0;
-  while (bits_done < 64) {
-    const int width = 64 - bits_done < kNmDigitBits ? 64 - bits_done : kNmDigitBits;
-    const int shift = 64 - bits_done - width;
-    for (int b = threadIdx.x; b < kNmBins; b += kBlock) s_hist[b] = 0;
-    __syncthreads();
-    for (int64_t c = threadIdx.x; c < num_items; c += kBlock) {
-      if (p[c] > 0.0f) continue;
-      const uint64_t k = cb_key(seed, row, c);
-      if (bits_done == 0 || (k >> (64 - bits_done)) == prefix)
-        atomicAdd(&s_hist[(int)((k >> shift) & ((1u << width) - 1))], 1);
-    }
-    __syncthreads();
-    if (wave == 0) {                                   // wave 0 finds the digit that holds the need-th key
+  // the digit (bin) that holds the need-th smallest key: wave 0 scans the histogram
+  auto find_digit = [&](int64_t want) {
+    if (wave == 0) {
       constexpr int PER = kNmBins / kWave;
       int local = 0;
       for (int b = 0; b < PER; ++b) local += s_hist[lane * PER + b];
-      int incl = local;                                // inclusive scan over the 64 lanes
+      int incl = local;
 #pragma unroll
       for (int d = 1; d < kWave; d <<= 1) {
         const int v = __shfl_up(incl, d, kWave);
         if (lane >= d) incl += v;
       }
       const int before_lane = incl - local;
-      if (before_lane < need && need <= incl) {        // exactly one lane
+      if (before_lane < want && want <= incl) {        // exactly one lane
         int run = before_lane;
         for (int b = 0; b < PER; ++b) {
-          const int h = s_hist[lane * PER + b];
-          if (run + h >= need) { s_sel_digit = lane * PER + b; s_sel_before = run; s_sel_count = h; break; }
-          run += h;
+          const int hcount = s_hist[lane * PER + b];
+          if (run + hcount >= want) { s_sel_digit = lane * PER + b; s_sel_before = run; s_sel_count = hcount; break; }
+          run += hcount;
         }
       }
     }
     __syncthreads();
-    prefix = (prefix << width) | (uint64_t)s_sel_digit;
-    bits_done += width;
-    need -= s_sel_before;
-    const bool exact = s_sel_count == need;            // every key of the selected bin is taken
+  };
+  find_digit(need);
+  uint64_t prefix = (uint64_t)s_sel_digit;             // the key bits fixed so far (top bits_done bits)
+  int bits_done = kNmDigitBits;
+  need -= s_sel_before;
+  const int in_bin = s_sel_count;
+  bool by_prefix = in_bin == need;                     // every key of the bin is taken: the prefix decides
+  uint64_t thr = 0;
+  __syncthreads();
+  if (!by_prefix && in_bin <= kNmListCap) {
+    // pass 2 (the usual case: a bin holds ~I / 2048 keys): gather the bin's keys, rank them in LDS
+    for (int64_t c = threadIdx.x; c < num_items; c += kNmThreads) {
+      if (p[c] > 0.0f) continue;
+      const uint64_t k = cb_key(seed, row, c);
+      if ((k >> (64 - kNmDigitBits)) == prefix) s_keys[atomicAdd(&s_nkeys, 1)] = k;
+    }
     __syncthreads();
-    if (exact) break;
+    for (int t = threadIdx.x; t < in_bin; t += kNmThreads) {
+      const unsigned long long mine = s_keys[t];
+      int rank = 0;
+      for (int j = 0; j < in_bin; ++j) rank += s_keys[j] < mine;
+      if (rank == (int)need - 1) s_thr = mine;         // keys are distinct (64 random bits)
+    }
+    __syncthreads();
+    thr = s_thr;
+  } else if (!by_prefix) {
+    // crowded bin (rows of millions of items): keep refining the prefix, 11 bits per pass
+    while (bits_done < 64) {
+      const int width = 64 - bits_done < kNmDigitBits ? 64 - bits_done : kNmDigitBits;
+      const int shift = 64 - bits_done - width;
+      for (int b = threadIdx.x; b < kNmBins; b += kNmThreads) s_hist[b] = 0;
+      __syncthreads();
+      for (int64_t c = threadIdx.x; c < num_items; c += kNmThreads) {
+        if (p[c] > 0.0f) continue;
+        const uint64_t k = cb_key(seed, row, c);
+        if ((k >> (64 - bits_done)) == prefix) atomicAdd(&s_hist[(int)((k >> shift) & ((1u << width) - 1))], 1);
+      }
+      __syncthreads();
+      find_digit(need);
+      prefix = (prefix << width) | (uint64_t)s_sel_digit;
+      bits_done += width;
+      need -= s_sel_before;
+      const bool exact = s_sel_count == need;
+      __syncthreads();
+      if (exact) break;
+    }
+    by_prefix = true;
   }
-  // keys whose top bits_done bits are <= prefix are selected (ties on all 64 bits — probability
-  // ~ I^2 / 2^64 — would over-select; not handled)
-  for (int64_t c = threadIdx.x; c < num_items; c += kBlock) {
+  // final pass: a non-positive item is selected when its key is <= the threshold key, or (prefix form)
+  // when its top bits_done bits are <= the prefix
+  for (int64_t c = threadIdx.x; c < num_items; c += kNmThreads) {
     float v = 0.0f;
     if (!(p[c] > 0.0f)) {
       const uint64_t k = cb_key(seed, row, c);
-      v = (bits_done >= 64 ? k : (k >> (64 - bits_done))) <= prefix ? 1.0f : 0.0f;
+      const bool sel = by_prefix ? (bits_done >= 64 ? k : (k >> (64 - bits_done))) <= prefix : k <= thr;
+      v = sel ? 1.0f : 0.0f;
     }
     o[c] = v;
   }
@@ -165,7 +210,7 @@ extern "C" int yr_negative_mask(const float* positives, int64_t B, int64_t num_i
   if (B < 0 || num_items <= 0 || neg_times < 0 || B > 0x7fffffff) return YR_ERR_BADARG;
   if (B == 0) return 0;
   if (!positives || !out || positives == out) return YR_ERR_BADARG;
-  hipLaunchKernelGGL(negative_mask_kernel, dim3((unsigned)B), dim3(kBlock), 0, (hipStream_t)stream, positives, num_items,
+  hipLaunchKernelGGL(negative_mask_kernel, dim3((unsigned)B), dim3(kNmThreads), 0, (hipStream_t)stream, positives, num_items,
                      neg_times, seed, out, err_flag);
   return launch_status();
 }
