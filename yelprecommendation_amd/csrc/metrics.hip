@@ -189,18 +189,22 @@ __global__ __launch_bounds__(kBlock) void rank_metrics_wave_kernel(const int64_t
 
 // out[0..3] = precision, recall, MAP, NDCG;  out[4] = users with a non-empty actual list;
 // out[5..8] = the four un-normalised sums, out[9] = n (what a user-sharded evaluation all-reduces)
-__global__ __launch_bounds__(kWave) void rank_metrics_finalize_kernel(const double* __restrict__ partial, int nblocks,
-                                                                      int64_t n, double* __restrict__ out) {
-  // lane l sums blocks l, l + 64, ... in order, then a fixed butterfly: deterministic
+__global__ __launch_bounds__(kBlock) void rank_metrics_finalize_kernel(const double* __restrict__ partial, int nblocks,
+                                                                       int64_t n, double* __restrict__ out) {
+  // thread t sums workgroup partials t, t + 256, ... in order; thread 0 adds the 256 thread sums in
+  // order: deterministic for a given n
+  __shared__ double s_sum[kBlock][5];
   double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int b = threadIdx.x; b < nblocks; b += kWave)
+  for (int b = threadIdx.x; b < nblocks; b += kBlock)
 #pragma unroll
     for (int q = 0; q < 5; ++q) s[q] += partial[(int64_t)b * 5 + q];
 #pragma unroll
-  for (int q = 0; q < 5; ++q)
-#pragma unroll
-    for (int m = kWave / 2; m >= 1; m >>= 1) s[q] += __shfl_xor(s[q], m, kWave);
+  for (int q = 0; q < 5; ++q) s_sum[threadIdx.x][q] = s[q];
+  __syncthreads();
   if (threadIdx.x != 0) return;
+  for (int t = 1; t < kBlock; ++t)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) s[q] += s_sum[t][q];
   out[0] = s[0] / (double)n;
   out[1] = s[1] / s[4];
   out[2] = s[2] / s[4];
@@ -235,6 +239,6 @@ extern "C" int yr_rank_metrics(const int64_t* topk, int64_t n, int k, const int6
     hipLaunchKernelGGL(rank_metrics_kernel, dim3(nblocks), dim3(kMetricBlock), 0, s, topk, n, k, pos_ptr, pos_idx,
                        pos_rows, workspace);
   }
-  hipLaunchKernelGGL(rank_metrics_finalize_kernel, dim3(1), dim3(kWave), 0, s, workspace, nblocks, n, out);
+  hipLaunchKernelGGL(rank_metrics_finalize_kernel, dim3(1), dim3(kBlock), 0, s, workspace, nblocks, n, out);
   return launch_status();
 }
