@@ -194,3 +194,28 @@ def test_sharded_trainer_matches_single_process(tmp_path, device):
                                    rtol=2e-3, atol=2e-5)
         np.testing.assert_allclose(o["I"], single.model.item_embedding.weight.detach().cpu().numpy(),
                                    rtol=2e-3, atol=2e-5)
+
+
+def test_eight_gpu_rank_shape_pull_equals_atomic(device):
+    """The per-rank problem of the 8-GPU run (3,958 users x 38,048 items, 2^20 triplets with
+    global_batch = 8 x 2^20: ~265 triplets per user, about half the user rows on the heavy path), in
+    the multi-GPU form of the step (dense item gradient in 2 chunks, separate item Adam): the pull form
+    equals the atomic form."""
+    from yelprecommendation_amd.bpr_step import BPRMFStep
+    g = torch.Generator(device=device).manual_seed(0)
+    nu, ni, d, B = 3958, 38048, 64, 1 << 20
+    U0 = torch.randn(nu, d, device=device, generator=g) * 0.05
+    I0 = torch.randn(ni, d, device=device, generator=g) * 0.05
+    u = torch.randint(0, nu, (B,), device=device, generator=g)
+    p = torch.randint(0, ni, (B,), device=device, generator=g)
+    n = torch.randint(0, ni, (B,), device=device, generator=g)
+    res = {}
+    for impl in ("pull", "atomic"):
+        st = BPRMFStep(U0.clone(), I0.clone(), lr=1e-3, impl=impl, split_item_update=(impl == "pull"), item_chunks=2)
+        for _ in range(2):
+            st.step(u, p, n, global_batch=8 * B)
+        st.check()
+        res[impl] = (st.U.clone(), st.I.clone(), st.epoch_loss())
+    torch.testing.assert_close(res["pull"][0], res["atomic"][0], rtol=1e-4, atol=2e-6)
+    torch.testing.assert_close(res["pull"][1], res["atomic"][1], rtol=1e-4, atol=2e-6)
+    assert abs(res["pull"][2] - res["atomic"][2]) < 1e-5 * abs(res["atomic"][2])
