@@ -2,6 +2,7 @@
 NumPy oracle: loss, both tables and the Adam state after several steps, for every supported
 width, with light-only, heavy-only and mixed row handling, uniform and popularity-skewed batches,
 empty and ragged batches, several partition tiles."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -162,3 +163,59 @@ def test_item_gradient_columns_sum_to_zero_at_full_size(device):
     assert col <= 1e-5 * scale, (col, scale)
     loss = st.epoch_loss()
     assert 0.6 < loss < 0.75                       # near-zero scores => loss ~ ln 2
+
+
+def test_integration_md_binding_stub_runs(device):
+    """The ctypes stub printed in INTEGRATION.md (what a maintainer of the reference would paste) is
+    executed as written against the built library and must reproduce BPRMFStep."""
+    import re
+    from yelprecommendation_amd.bpr_step import BPRMFStep
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# engine_binding\.py.*?)```", text, re.S).group(1)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(root)                                    # the stub loads the library by its repo-relative path
+    try:
+        exec(compile(block, "INTEGRATION.md", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    rs = np.random.RandomState(8)
+    nu, ni, d, B = 200, 300, 64, 5000
+    U = (rs.standard_normal((nu, d)) * 0.1).astype(np.float32)
+    I = (rs.standard_normal((ni, d)) * 0.1).astype(np.float32)
+
+    class _Emb:
+        def __init__(self, w): self.weight = torch.nn.Parameter(torch.from_numpy(w.copy()).to(device))
+
+    class _Model:
+        def __init__(self): self.user_embedding, self.item_embedding = _Emb(U), _Emb(I)
+
+    stub = ns["FusedBPRStep"](_Model(), lr=1e-3)
+    ref = BPRMFStep(torch.from_numpy(U).to(device), torch.from_numpy(I).to(device), lr=1e-3, impl="pull")
+    for _ in range(3):
+        t = [torch.from_numpy(rs.randint(0, hi, B).astype(np.int64)).to(device) for hi in (nu, ni, ni)]
+        stub(*t)
+        ref.step(*t)
+    torch.testing.assert_close(stub.U, ref.U, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(stub.I, ref.I, rtol=1e-4, atol=1e-6)
+    assert abs(float(stub.loss_sum.item()) - ref.epoch_loss()) < 1e-5
+    assert int(stub.flag.item()) == 0
+    # the evaluation stub of the same document (scores + mask + top-k + metrics through the C ABI)
+    from yelprecommendation_amd import engine
+    block2 = re.search(r"```python\n(_lib\.yr_mf_eval_topk_workspace_bytes.*?)```", text, re.S).group(1)
+    exec(compile(block2, "INTEGRATION.md#evaluate", "exec"), ns)
+    model = _Model()
+    model.user_embedding.weight.data, model.item_embedding.weight.data = stub.U, stub.I
+    users = torch.arange(nu, device=device)
+    lists = [np.sort(rs.choice(ni, size=rs.randint(0, 30), replace=False)) for _ in range(nu)]
+    mptr = np.zeros(nu + 1, np.int64); mptr[1:] = np.cumsum([len(l) for l in lists])
+    midx = np.concatenate(lists).astype(np.int64)
+    pos = [rs.choice(ni, size=rs.randint(0, 12), replace=False) for _ in range(nu)]
+    pptr = np.zeros(nu + 1, np.int64); pptr[1:] = np.cumsum([len(l) for l in pos])
+    pidx = np.concatenate(pos).astype(np.int64)
+    t = lambda a: torch.from_numpy(a).to(device)
+    got = ns["evaluate"](model, users, t(mptr), t(midx), t(pptr), t(pidx), 10)
+    top = engine.mf_eval_topk(stub.U, stub.I, users, t(mptr), t(midx), 10)
+    want = engine.rank_metrics(top, t(pptr), t(pidx))[:4].tolist()
+    np.testing.assert_allclose(got, want, rtol=1e-12)
