@@ -12,52 +12,59 @@ from ...utils import logger
 from .data_pipeline import DataPipeline
 
 
+def _cut(history):
+    """train / valid / test parts of one (already shuffled) history: int(0.8 n) go to train+valid, of
+    which int(0.75 .) to train (cdae_data_pipeline.py:30-32)."""
+    n_train_valid = int(0.8 * len(history))
+    n_train = int(0.75 * n_train_valid)
+    return history[:n_train], history[n_train:n_train_valid], history[n_train_valid:]
+
+
+def _mask(num_items, ids):
+    m = np.zeros(num_items, dtype=np.int32)
+    m[ids] = 1
+    return m
+
+
 class CDAEDataPipeline(DataPipeline):
 
-    def __init__(self, cfg):
-        super().__init__(cfg)
-
     def split(self, df):
+        """``df``: the frame of :meth:`preprocess` (column 0 = user id, then one 0/1 column per item).
+        Returns three dicts keyed by user id (train / valid / test), each value holding the dense
+        masks the matching :class:`CDAEDataset` mode reads."""
         logger.info('start random user split...')
+        table = df.values
+        num_items = table.shape[1] - 1
         train_data, valid_data, test_data = {}, {}, {}
-        values = df.values
-        for row in values:
-            user_id = int(row[0])
-            hist = row[1:]
-            user_history = np.argwhere(hist).reshape(-1)
-            np.random.shuffle(user_history)
-            train_samples, test_samples = np.split(user_history, [int(0.8 * len(user_history))])
-            train_samples, valid_samples = np.split(train_samples, [int(0.75 * len(train_samples))])
-            masks = []
-            for samples in (train_samples, valid_samples, test_samples, np.union1d(train_samples, valid_samples)):
-                m = np.zeros(hist.shape[0], dtype=np.int32)
-                m[samples] = 1
-                masks.append(m)
-            train_mask, valid_mask, test_mask, train_valid_mask = masks
-            train_data[user_id] = {'input_mask': train_mask}
-            valid_data[user_id] = {'input_mask': train_mask, 'valid_mask': valid_mask}
-            test_data[user_id] = {'input_mask': train_valid_mask, 'test_mask': test_mask}
+        for row in table:
+            user = int(row[0])
+            history = np.flatnonzero(row[1:])
+            np.random.shuffle(history)               # one global-RNG shuffle per user, in frame order
+            train_ids, valid_ids, test_ids = _cut(history)
+            seen_in_training = _mask(num_items, train_ids)
+            train_data[user] = {'input_mask': seen_in_training}
+            valid_data[user] = {'input_mask': seen_in_training, 'valid_mask': _mask(num_items, valid_ids)}
+            test_data[user] = {'input_mask': _mask(num_items, np.concatenate([train_ids, valid_ids])),
+                               'test_mask': _mask(num_items, test_ids)}
         logger.info("done")
         return train_data, valid_data, test_data
 
     def preprocess(self) -> pd.DataFrame:
         logger.info("start preprocessing...")
-        df = self._load_df()
-        training_set = self._transform_into_training_set(df)
+        wide = self._transform_into_training_set(self._load_df())
         logger.info("done")
-        return training_set
+        return wide
 
     def _load_df(self):
         logger.info("load df...")
-        return pd.read_csv(os.path.join(self.cfg.data_dir, 'yelp_interactions.tsv'), sep='\t', index_col=False)
+        path = os.path.join(self.cfg.data_dir, 'yelp_interactions.tsv')
+        return pd.read_csv(path, sep='\t', index_col=False)
 
     def _transform_into_training_set(self, df):
-        # reference cdae_data_pipeline.py:78-90
+        """users x items 0/1 frame with the user id as first column (cdae_data_pipeline.py:78-90):
+        pivot on the rating, missing -> 0, any rating -> 1."""
         logger.info("transform df into training set...")
-        item_inputs = df.pivot_table(index='user_id', columns=['business_id'], values=['rating'])
-        training_set = item_inputs.droplevel(0, 1)
-        training_set = training_set.fillna(0)
-        training_set = training_set.mask(training_set > 0, 1)
-        training_set = training_set.reset_index()
-        training_set.index.name = None
-        return training_set
+        wide = df.pivot_table(index='user_id', columns=['business_id'], values=['rating']).droplevel(0, axis=1).fillna(0)
+        wide = wide.mask(wide > 0, 1).reset_index()
+        wide.index.name = None
+        return wide

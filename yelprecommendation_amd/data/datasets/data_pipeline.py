@@ -1,15 +1,18 @@
-"""reference data/datasets/data_pipeline.py:4-23 — abstract base of the data pipelines."""
-from abc import ABC, abstractmethod
+"""Interface of the three data pipelines (the reference's ``DataPipeline``,
+data/datasets/data_pipeline.py:4-23): they are built from the run config, ``preprocess()`` yields
+the frame a model family works on and ``split()`` cuts it into the train / valid / test parts."""
+import abc
 
 
-class DataPipeline(ABC):
+class DataPipeline(abc.ABC):
+
     def __init__(self, cfg):
         self.cfg = cfg
 
-    @abstractmethod
-    def split(self):
-        pass
-
-    @abstractmethod
+    @abc.abstractmethod
     def preprocess(self):
-        pass
+        """Load the interactions and bring them into the family's input form."""
+
+    @abc.abstractmethod
+    def split(self):
+        """Cut the preprocessed data into train / valid / test parts."""

@@ -1,20 +1,24 @@
-"""Drop-in for reference models/base_model.py:6-18 (same class, same hooks)."""
-from abc import ABC, abstractmethod
+"""Common base of the three models (the reference's ``BaseModel``, models/base_model.py:6-18).
 
-import torch.nn as nn
+Kept as an ``nn.Module`` so ``.to()``, ``.train()/.eval()``, ``.parameters()`` and
+``state_dict()/load_state_dict()`` behave as the reference's trainers expect
+(trainers/base_trainer.py:110,157).  The one helper the subclasses use, ``_activation_module``,
+maps a config string to a module; an unknown name yields ``None`` exactly as in the reference
+(models/base_model.py:10-14), and subclasses must provide ``_init_weights``.
+"""
+import abc
+
+from torch import nn
+
+_ACTIVATIONS = {"sigmoid": nn.Sigmoid, "identity": nn.Identity}
 
 
-class BaseModel(nn.Module, ABC):
-    def __init__(self, *args, **kwargs) -> None:
-        super().__init__(*args, **kwargs)
+class BaseModel(nn.Module, abc.ABC):
 
-    def _activation_module(self, function_name: str) -> nn.Module:
-        # reference models/base_model.py:10-14 (returns None for any other name)
-        if function_name == 'sigmoid':
-            return nn.Sigmoid()
-        elif function_name == 'identity':
-            return nn.Identity()
+    def _activation_module(self, function_name: str):
+        make = _ACTIVATIONS.get(function_name)
+        return make() if make is not None else None
 
-    @abstractmethod
+    @abc.abstractmethod
     def _init_weights(self):
-        pass
+        """Initialise the parameters (called by the subclass constructor where the reference does)."""

@@ -14,49 +14,51 @@ from .. import optim
 from ..utils import logger
 
 
+# position of every selectable metric in the (valid_loss, precision, recall, map, ndcg) tuples and
+# whether smaller is better (reference base_trainer.py:117-141)
+_BEST_METRIC = {"loss": (0, True), "precision": (1, False), "recall": (2, False), "map": (3, False), "ndcg": (4, False)}
+_OPTIMIZERS = {"adam": optim.Adam, "adamw": optim.AdamW, "sgd": optim.SGD}
+
+
 class BaseTrainer(ABC):
+
     def __init__(self, cfg) -> None:
         self.cfg = cfg
-        self.device: torch.device = self._device(self.cfg.device)
-        os.makedirs(self.cfg.model_dir, exist_ok=True)
+        self.device: torch.device = self._device(cfg.device)
+        os.makedirs(cfg.model_dir, exist_ok=True)
 
     def _device(self, device_name: str) -> torch.device:
-        # reference base_trainer.py:20-25.  'cuda' is the ROCm device on MI355X.  'cpu' is
-        # still a legal name (the reference's default) but the HIP ops refuse CPU tensors,
-        # so a cpu run fails loudly at the first model call instead of silently falling back.
-        if device_name.lower() in ('cpu', 'cuda',):
-            return torch.device(device_name.lower())
-        else:
+        """'cuda' is the ROCm device on MI355X.  'cpu' stays a legal name (the reference's default,
+        base_trainer.py:20-25) but the HIP ops refuse CPU tensors, so such a run fails loudly at the
+        first model call instead of silently falling back; any other name logs and yields cpu."""
+        name = device_name.lower()
+        if name not in ("cpu", "cuda"):
             logger.error(f"Not supported device: {device_name}")
-            return torch.device('cpu')
+            name = "cpu"
+        return torch.device(name)
 
     def _model(self, model_name: str) -> Module:
-        # reference base_trainer.py:27-32
-        if model_name.lower() in ('test',):
-            return type("TestModel", (Module,), {"forward": (lambda self, x: x)})()
-        else:
+        # reference base_trainer.py:27-32: only the placeholder name 'test' is known at this level
+        if model_name.lower() != "test":
             logger.error(f"Not implemented model: {model_name}")
             raise NotImplementedError(f"Not implemented model: {model_name}")
+        return type("TestModel", (Module,), {"forward": (lambda self, x: x)})()
 
     def _optimizer(self, optimizer_name: str, model: Module, learning_rate: float, weight_decay: float = 0):
-        # reference base_trainer.py:34-43
-        if optimizer_name.lower() == 'adam':
-            return optim.Adam(model.parameters(), lr=learning_rate, weight_decay=weight_decay)
-        elif optimizer_name.lower() == 'adamw':
-            return optim.AdamW(model.parameters(), lr=learning_rate, weight_decay=weight_decay)
-        elif optimizer_name.lower() == 'sgd':
-            return optim.SGD(model.parameters(), lr=learning_rate, weight_decay=weight_decay)
-        else:
+        """adam / adamw / sgd over all parameters with torch's default betas / eps (reference
+        base_trainer.py:34-43), as the dense HIP-backed optimizers of :mod:`..optim`."""
+        make = _OPTIMIZERS.get(optimizer_name.lower())
+        if make is None:
             logger.error(f"Optimizer Not Exists: {optimizer_name}")
             raise NotImplementedError(f"Optimizer Not Exists: {optimizer_name}")
+        return make(model.parameters(), lr=learning_rate, weight_decay=weight_decay)
 
     def _loss(self, loss_name: str):
         # reference base_trainer.py:45-50
-        if loss_name.lower() == 'bce':
-            return torch.nn.BCELoss()
-        else:
+        if loss_name.lower() != "bce":
             logger.error(f"Loss Not Exists: {loss_name}")
             raise NotImplementedError(f"Loss Not Exists: {loss_name}")
+        return torch.nn.BCELoss()
 
     def run(self, train_dataloader, valid_dataloader):
         # reference base_trainer.py:52-115 (validate() returns loss + the four metrics)
@@ -83,22 +85,14 @@ class BaseTrainer(ABC):
                     f"precision@K : {p:.4f} / Recall@K: {r:.4f} / MAP@K: {m:.4f} / NDCG@K: {n:.4f}")
 
     def _is_surpass_best_metric(self, **metric) -> bool:
-        # reference base_trainer.py:117-141
-        (valid_loss, valid_precision_at_k, valid_recall_at_k, valid_map_at_k, valid_ndcg_at_k) = metric['current']
-        (best_valid_loss, best_valid_precision_at_k, best_valid_recall_at_k, best_valid_map_at_k,
-         best_valid_ndcg_at_k) = metric['best']
-        if self.cfg.best_metric == 'loss':
-            return valid_loss < best_valid_loss
-        elif self.cfg.best_metric == 'precision':
-            return valid_precision_at_k > best_valid_precision_at_k
-        elif self.cfg.best_metric == 'recall':
-            return valid_recall_at_k > best_valid_recall_at_k
-        elif self.cfg.best_metric == 'map':
-            return valid_map_at_k > best_valid_map_at_k
-        elif self.cfg.best_metric == 'ndcg':
-            return valid_ndcg_at_k > best_valid_ndcg_at_k
-        else:
+        """``current`` beats ``best`` on ``cfg.best_metric`` (both are (valid_loss, precision, recall,
+        map, ndcg) tuples; an unknown metric name never improves — reference base_trainer.py:117-141)."""
+        choice = _BEST_METRIC.get(self.cfg.best_metric)
+        if choice is None:
             return False
+        position, smaller_is_better = choice
+        current, best = metric['current'][position], metric['best'][position]
+        return current < best if smaller_is_better else current > best
 
     @abstractmethod
     def train(self, train_dataloader) -> float:
