@@ -111,3 +111,36 @@ def test_sampler_from_dataset_avoids_positives(g):
     keys = set((int(a) * pipe.num_items + int(b)) for a, b in
                zip(np.r_[train.user_id.values, valid.user_id.values], np.r_[train.business_id.values, valid.business_id.values]))
     assert not any((int(a) * pipe.num_items + int(b)) in keys for a, b in zip(u.tolist(), n.tolist()))
+
+
+def test_cdae_pipeline_reproduces_reference_split(golden_dir):
+    """CDAEDataPipeline (pivot + per-user shuffle + 60/20/20 cut) against the masks the REFERENCE
+    pipeline produced for the same frame under the same NumPy seed (tests/golden/cdae_small.npz,
+    written by make_golden.py: make_frame(96, 200, 12.0, seed=99), np.random.seed(1))."""
+    from yelprecommendation_amd.data.datasets.cdae_data_pipeline import CDAEDataPipeline
+    from yelprecommendation_amd.data.datasets.cdae_dataset import CDAEDataset
+    from yelprecommendation_amd.data.synthetic import make_frame
+    from yelprecommendation_amd.utils import make_config
+    g = np.load(os.path.join(golden_dir, "cdae_small.npz"))
+    pipe = CDAEDataPipeline(make_config("CDAE", device="cpu", model_dir="/tmp/yr_cdae_pipe"))
+    frame = pipe._transform_into_training_set(make_frame(96, 200, 12.0, seed=99))
+    assert frame.shape == (int(g["num_users"]), int(g["num_items"]) + 1)
+    np.random.seed(1)
+    train_data, valid_data, test_data = pipe.split(frame)
+    users = sorted(train_data)
+    assert users == list(range(int(g["num_users"])))
+    np.testing.assert_array_equal(np.stack([train_data[u]["input_mask"] for u in users]), g["train_input"])
+    np.testing.assert_array_equal(np.stack([valid_data[u]["valid_mask"] for u in users]), g["valid_mask"])
+    np.testing.assert_array_equal(np.stack([valid_data[u]["input_mask"] for u in users]), g["train_input"])
+    np.testing.assert_array_equal(np.stack([test_data[u]["input_mask"] for u in users]), g["test_input"])
+    np.testing.assert_array_equal(np.stack([test_data[u]["test_mask"] for u in users]), g["test_mask"])
+    # the dataset's negatives: right count, never a positive, one np.random.choice per fetched user
+    ds = CDAEDataset(valid_data, "valid", neg_times=2)
+    np.random.seed(3)
+    sample = ds[5]
+    pos = sample["input_mask"] + sample["valid_mask"]
+    assert sample["negative_mask"].sum() == 2 * pos.sum() and float((sample["negative_mask"] * pos).sum()) == 0.0
+    np.random.seed(3)
+    want = np.random.choice(np.flatnonzero(1 - pos), int(pos.sum()) * 2, replace=False)
+    np.testing.assert_array_equal(np.flatnonzero(sample["negative_mask"]), np.sort(want))
+    assert set(CDAEDataset(test_data, "test")[5]) == {"user_id", "input_mask", "test_mask"}
