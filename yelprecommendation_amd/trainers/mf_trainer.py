@@ -182,7 +182,9 @@ class MFTrainer(BaseTrainer):
         if key not in self._eval_cache:
             users = np.asarray(eval_data.index.values, dtype=np.int64)
             pos = [list(x) for x in eval_data['pos_items']]
-            masks = [list(x) for x in eval_data['mask_items']]
+            # ascending ids inside every mask list: what the fused evaluation kernel walks with a cursor
+            # (sorted once here instead of on the device at every evaluate())
+            masks = [sorted(x) for x in eval_data['mask_items']]
             if self.world_size > 1:                            # this rank scores the users it owns
                 keep = np.flatnonzero(self.shard.mine(users))
                 users, pos, masks = users[keep], [pos[k] for k in keep], [masks[k] for k in keep]
@@ -196,9 +198,10 @@ class MFTrainer(BaseTrainer):
 
     def recommend(self, users, mask_ptr, mask_idx):
         """Top-``top_n`` item ids per user, masked items excluded ([n_users, top_n] int64, device)."""
-        return engine.mf_recommend(self.model.user_embedding.weight.detach(),
-                                   self.model.item_embedding.weight.detach(),
-                                   users, mask_ptr, mask_idx, self.cfg.top_n)
+        U, I = self.model.user_embedding.weight.detach(), self.model.item_embedding.weight.detach()
+        if self.cfg.top_n <= 16:                          # fused scores + mask + top-k; masks are pre-sorted
+            return engine.mf_eval_topk(U, I, users.contiguous(), mask_ptr, mask_idx, self.cfg.top_n)
+        return engine.mf_recommend(U, I, users, mask_ptr, mask_idx, self.cfg.top_n, fused=False)
 
     def evaluate(self, eval_data, mode='valid') -> tuple:
         # reference mf_trainer.py:134-161
