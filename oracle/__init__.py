@@ -18,5 +18,8 @@ reference (torch ATen, pinned ``torch==2.2.2`` in poetry.lock:2187-2188; not und
 reference itself in the build container (``tests/golden/make_golden.py`` is the
 generating script; torch 2.10 / numpy 2.2 / sklearn 1.7 — versions are stored in
 each fixture).  ``tests/test_oracle_*.py`` check every oracle function against
-those fixtures.
+those fixtures.  ``cdae_batches.py`` (the CPU statement of the two CDAE batch kernels) is pinned
+differently: its dense rows against the reference-style pipeline's masks, its negative masks
+through the law of ``np.random.choice(.., replace=False)`` (tests/test_cdae_batches.py) — the random
+stream itself cannot be the reference's.
 """

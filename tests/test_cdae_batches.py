@@ -1,10 +1,15 @@
-"""Host logic of the device-side CDAE batches (pure torch ops: runs on CPU tensors here, on the GPU in
-training): the sparse store reproduces the dense masks of the reference-style pipeline, the split
-arithmetic is the reference's, and negative masks have the reference's law."""
+"""Host logic of the device-side CDAE batches: the sparse per-user store (index bookkeeping in torch, any
+device) reproduces the dense masks of the reference-style pipeline, its split arithmetic is the
+reference's, and the CPU statement of the negative-mask kernel (oracle/cdae_batches.py) has the
+reference's law.  The HIP kernels themselves are compared with these definitions in test_gpu_cdae.py;
+without a GPU the product loader refuses to build batches."""
 import numpy as np
 import pandas as pd
 import torch
 
+import pytest
+
+from oracle import cdae_batches as ocb
 from yelprecommendation_amd.data.cdae_batches import CDAEBatchLoader, CDAEInteractions
 from yelprecommendation_amd.data.datasets.cdae_data_pipeline import CDAEDataPipeline
 from yelprecommendation_amd.data.datasets.cdae_dataset import CDAEDataset
@@ -22,55 +27,56 @@ def _pipeline_split(seed=3):
     return df, pipe.split(frame)
 
 
-def test_sparse_store_reproduces_dense_pipeline_batches():
+def _dense(data, part, users):
+    if part == "train_valid":
+        return torch.clamp(_dense(data, "train", users) + _dense(data, "valid", users), max=1.0)
+    ptr, idx = data.csr(part)
+    return ocb.dense_rows(ptr, idx, users, data.num_items)
+
+
+def test_sparse_store_reproduces_dense_pipeline_masks():
     df, (train_data, valid_data, test_data) = _pipeline_split()
     data = CDAEInteractions.from_split(train_data, valid_data, test_data)
     assert data.num_users == len(train_data) and data.num_items == len(train_data[0]["input_mask"])
-    for mode, ref_ds in (("train", CDAEDataset(train_data, "train", 1)), ("valid", CDAEDataset(valid_data, "valid", 1)),
-                         ("test", CDAEDataset(test_data, "test"))):
-        loader = CDAEBatchLoader(data, mode, batch_size=16, neg_times=1)
-        assert len(loader) == 4
-        seen = 0
-        for batch in loader:
-            for r, u in enumerate(batch["user_id"].tolist()):
-                want = ref_ds[u]
-                np.testing.assert_array_equal(batch["input_mask"][r].numpy(), want["input_mask"])
-                for key in ("valid_mask", "test_mask"):
-                    if key in want:
-                        np.testing.assert_array_equal(batch[key][r].numpy(), want[key])
-                seen += 1
-        assert seen == data.num_users
+    users = torch.arange(data.num_users)
+    dense = {p: _dense(data, p, users).numpy() for p in ("train", "valid", "test", "train_valid")}
+    for u in range(data.num_users):
+        np.testing.assert_array_equal(dense["train"][u], train_data[u]["input_mask"])
+        np.testing.assert_array_equal(dense["valid"][u], valid_data[u]["valid_mask"])
+        np.testing.assert_array_equal(dense["train_valid"][u], test_data[u]["input_mask"])
+        np.testing.assert_array_equal(dense["test"][u], test_data[u]["test_mask"])
+    # the merged train | valid CSR the test-time batches index (ids ascending inside a user)
+    ptr, idx = data.csr("train_valid")
+    np.testing.assert_array_equal(ocb.dense_rows(ptr, idx, users, data.num_items).numpy(), dense["train_valid"])
+    assert all(bool((idx[ptr[u]:ptr[u + 1]][1:] > idx[ptr[u]:ptr[u + 1]][:-1]).all()) for u in range(data.num_users))
+    # batches are built by HIP kernels only: a CPU store cannot be iterated
+    from yelprecommendation_amd._lib import EngineError
+    with pytest.raises(EngineError):
+        next(iter(CDAEBatchLoader(data, "train", batch_size=16, neg_times=1)))
 
 
-def test_negative_masks_have_the_reference_law():
+def test_negative_mask_definition_has_the_reference_law():
     df, (train_data, valid_data, test_data) = _pipeline_split()
     data = CDAEInteractions.from_split(train_data, valid_data, test_data)
-    for mode in ("train", "valid"):
-        a = list(CDAEBatchLoader(data, mode, batch_size=25, neg_times=3, seed=1))
-        b = list(CDAEBatchLoader(data, mode, batch_size=25, neg_times=3, seed=2))
-        differ = False
-        for x, y in zip(a, b):
-            pos = x["input_mask"] + (x["valid_mask"] if mode == "valid" else 0)
-            neg = x["negative_mask"]
-            assert set(neg.unique().tolist()) <= {0.0, 1.0}
-            assert float((neg * pos).sum()) == 0.0                        # never a positive (train + valid in valid mode)
-            torch.testing.assert_close(neg.sum(1), 3 * pos.sum(1))         # exact count, no replacement
-            differ |= not torch.equal(neg, y["negative_mask"])
-        assert differ                                                      # the seed matters
+    users = torch.arange(data.num_users)
+    for pos in (_dense(data, "train", users), _dense(data, "train", users) + _dense(data, "valid", users)):
+        a = ocb.negative_mask(pos, 3, torch.Generator().manual_seed(1))
+        b = ocb.negative_mask(pos, 3, torch.Generator().manual_seed(2))
+        assert set(a.unique().tolist()) <= {0.0, 1.0}
+        assert float((a * pos).sum()) == 0.0                              # never a positive
+        torch.testing.assert_close(a.sum(1), 3 * pos.sum(1))               # exact count, no replacement
+        assert not torch.equal(a, b)                                       # the seed matters
     # uniformity: over many draws every non-positive item of a user is picked equally often
     pos = torch.zeros(1, 40); pos[0, :4] = 1
-    loader = CDAEBatchLoader(data, "train", neg_times=2, seed=7)
-    hits = sum(loader.negative_mask(pos) for _ in range(3000))[0]
+    gen = torch.Generator().manual_seed(7)
+    hits = sum(ocb.negative_mask(pos, 2, gen) for _ in range(3000))[0]
     assert float(hits[:4].sum()) == 0.0
     freq = hits[4:] / 3000.0                                               # expected 8 / 36
     assert float((freq - 8 / 36).abs().max()) < 0.04
     # asking for more negatives than exist fails like np.random.choice(replace=False)
     crowded = torch.ones(1, 10); crowded[0, 0] = 0
-    try:
-        loader.negative_mask(crowded)
-        raise AssertionError("expected ValueError")
-    except ValueError:
-        pass
+    with pytest.raises(ValueError):
+        ocb.negative_mask(crowded, 2)
 
 
 def test_split_from_interactions_follows_reference_arithmetic():
@@ -85,8 +91,8 @@ def test_split_from_interactions_follows_reference_arithmetic():
         n_tv = int(0.8 * n); n_tr = int(0.75 * n_tv)                       # cdae_data_pipeline.py:30-32
         assert (tr[user], va[user], te[user]) == (n_tr, n_tv - n_tr, n - n_tv)
         rows = torch.tensor([user])
-        parts = [set(data.dense(p, rows)[0].nonzero().flatten().tolist()) for p in CDAEInteractions.PARTS]
+        parts = [set(_dense(data, p, rows)[0].nonzero().flatten().tolist()) for p in CDAEInteractions.PARTS]
         assert parts[0] | parts[1] | parts[2] == hist[user] and not (parts[0] & parts[1]) and not (parts[1] & parts[2])
-        assert set(data.dense("train_valid", rows)[0].nonzero().flatten().tolist()) == parts[0] | parts[1]
+        assert set(_dense(data, "train_valid", rows)[0].nonzero().flatten().tolist()) == parts[0] | parts[1]
     other = CDAEInteractions.from_interactions(u, i, nu, ni, seed=6)
-    assert not torch.equal(other.dense("train", torch.arange(nu)), data.dense("train", torch.arange(nu)))
+    assert not torch.equal(_dense(other, "train", torch.arange(nu)), _dense(data, "train", torch.arange(nu)))

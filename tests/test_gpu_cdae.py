@@ -255,8 +255,10 @@ def test_device_batches_match_host_definitions(device):
     cpu = CDAEInteractions.from_interactions(torch.from_numpy(u), torch.from_numpy(i), nu, ni, seed=3, device="cpu")
     gpu = CDAEInteractions(nu, ni, {k: cpu._csr[k] for k in CDAEInteractions.PARTS}, device)
     users = torch.from_numpy(rs.permutation(nu)[:77].astype(np.int64))
+    from oracle import cdae_batches as ocb
     for part in ("train", "valid", "test", "train_valid"):
-        torch.testing.assert_close(gpu.dense(part, users.to(device)).cpu(), cpu.dense(part, users), rtol=0, atol=0)
+        want = sum(ocb.dense_rows(*cpu.csr(p), users, ni) for p in (("train", "valid") if part == "train_valid" else (part,)))
+        torch.testing.assert_close(gpu.dense(part, users.to(device)).cpu(), want.clamp(max=1.0), rtol=0, atol=0)
     for mode in ("train", "valid"):
         batches = list(CDAEBatchLoader(gpu, mode, batch_size=64, neg_times=5, seed=11))
         again = list(CDAEBatchLoader(gpu, mode, batch_size=64, neg_times=5, seed=11))

@@ -14,8 +14,9 @@ Negative masks have the reference's law — exactly ``neg_times * positives`` di
 items per user, every subset equally likely (random keys + per-row order statistic) — but from the
 device RNG, so parity tests replay recorded masks instead (tests/test_gpu_cdae.py).
 
-On the GPU both pieces are HIP kernels (``yr_csr_rows_to_dense``, ``yr_negative_mask``:
-csrc/cdae_batches.hip); on CPU tensors (host-logic tests) the same definitions run as torch ops.
+Both pieces are HIP kernels (``yr_csr_rows_to_dense``, ``yr_negative_mask``: csrc/cdae_batches.hip);
+the store may be built on any device (index bookkeeping in torch), but batches exist on the GPU only —
+on CPU tensors the engine raises.  The CPU statement of the two kernels lives in oracle/cdae_batches.py.
 """
 import torch
 
@@ -107,21 +108,11 @@ class CDAEInteractions:
     def dense(self, part, users):
         """[len(users), num_items] float32 0/1 rows of ``part`` ('train', 'valid', 'test' or
         'train_valid' = train | valid, the test-time input of cdae_data_pipeline.py:38)."""
-        parts = ("train", "valid") if part == "train_valid" else (part,)
-        if self.device.type == "cuda":
-            out = None
-            for p in parts:
-                ptr, idx = self._csr[p]
-                out = engine.csr_rows_to_dense(ptr, idx, users.contiguous(), self.num_items, out=out,
-                                               accumulate=out is not None)
-            return out
-        out = torch.zeros((users.numel(), self.num_items), dtype=torch.float32, device=self.device)
-        for p in parts:
+        out = None
+        for p in (("train", "valid") if part == "train_valid" else (part,)):
             ptr, idx = self._csr[p]
-            lo, cnt = ptr[users], ptr[users + 1] - ptr[users]
-            rows = torch.repeat_interleave(torch.arange(users.numel(), device=self.device), cnt)
-            offs = torch.arange(rows.numel(), device=self.device) - torch.repeat_interleave(torch.cumsum(cnt, 0) - cnt, cnt)
-            out[rows, idx[lo[rows] + offs]] = 1.0
+            out = engine.csr_rows_to_dense(ptr, idx, users.contiguous(), self.num_items, out=out,
+                                           accumulate=out is not None)
         return out
 
 
@@ -139,7 +130,7 @@ class CDAEBatchLoader:
         self.data, self.mode, self.batch_size, self.neg_times, self.shuffle = data, mode, int(batch_size), neg_times, shuffle
         self._gen = torch.Generator(device=data.device).manual_seed(seed)
         self._seeds = torch.Generator().manual_seed(seed)          # host generator: per-batch kernel seeds
-        self._flag = engine.new_error_flag(data.device) if data.device.type == "cuda" else None
+        self._flag = engine.new_error_flag(data.device) if data.device.type == "cuda" else None   # cpu store: iterating raises
 
     def __len__(self):
         return (self.data.num_users + self.batch_size - 1) // self.batch_size
@@ -147,24 +138,8 @@ class CDAEBatchLoader:
     def negative_mask(self, positives):
         """Exactly ``neg_times * positives`` distinct non-positive items per row, uniformly: the
         items with the smallest of I i.i.d. random keys among the non-positives."""
-        if positives.is_cuda:
-            seed = int(torch.randint(0, 1 << 62, (1,), generator=self._seeds).item())
-            return engine.negative_mask(positives.contiguous(), self.neg_times, seed, err_flag=self._flag)
-        n = (positives.sum(dim=1) * self.neg_times).long()
-        room = positives.shape[1] - positives.sum(dim=1).long()
-        if bool((n > room).any()):
-            # np.random.choice(..., replace=False) raises in the reference (cdae_dataset.py:27)
-            raise ValueError("Cannot take a larger sample than population when 'replace=False'")
-        kmax = int(n.max()) if n.numel() else 0
-        if kmax == 0:
-            return torch.zeros_like(positives)
-        # float64 keys: with float32 a row of 38k keys holds dozens of ties, and a tie AT the
-        # threshold would break the exact count
-        keys = torch.rand(positives.shape, generator=self._gen, device=positives.device, dtype=torch.float64)
-        keys = torch.where(positives > 0, torch.full_like(keys, 2.0), keys)
-        smallest = torch.topk(keys, kmax, dim=1, largest=False, sorted=True).values
-        thr = smallest.gather(1, (n - 1).clamp_(min=0)[:, None])
-        return ((keys <= thr) & (n[:, None] > 0)).float()
+        seed = int(torch.randint(0, 1 << 62, (1,), generator=self._seeds).item())
+        return engine.negative_mask(positives.contiguous(), self.neg_times, seed, err_flag=self._flag)
 
     def __iter__(self):
         d = self.data
