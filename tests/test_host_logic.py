@@ -151,3 +151,12 @@ def test_numpy_generator_shape():
     assert u.min() == 0 and u.max() == 299 and i.max() == 249 and set(np.unique(r)) <= {1, 2, 3, 4, 5}
     assert np.bincount(i).min() >= 5 and np.bincount(u).min() >= 5
     assert len(set(zip(u.tolist(), i.tolist()))) == len(u)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No silent fallback: with the shared library absent, loading raises and names the build command."""
+    from yelprecommendation_amd import _lib
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(str(tmp_path), "libyelprec_engine.so"))
+    monkeypatch.setattr(_lib, "_lib", None)                          # forget the cached handle for this test
+    with pytest.raises(_lib.EngineError, match="not found"):
+        _lib.load()
