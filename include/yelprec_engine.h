@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 18
+#define YR_ENGINE_VERSION 19
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -41,7 +41,7 @@ extern "C" {
 #define YR_FLAG_BAD_USER 1
 #define YR_FLAG_BAD_ITEM 2
 
-#define YR_PULL_USER_PHASE 1 /* yr_bpr_mf_pull_apply: user pass + coefficient gather      */
+#define YR_PULL_USER_PHASE 1 /* yr_bpr_mf_pull_apply: owner pass over the user rows          */
 #define YR_PULL_ITEM_PHASE 2 /* yr_bpr_mf_pull_apply: item pass over [item_row_begin, end) */
 
 #define YR_OPT_ADAM  0 /* torch.optim.Adam  : grad += wd * p               */
@@ -99,16 +99,20 @@ int yr_bpr_mf_fwd_bwd(const float *U, const float *I,
                       float *loss_partials, int32_t *err_flag, void *stream);
 
 /* ---------------------------------------------------------------------------
- * One whole BPR-MF optimisation step, pull-based (no float atomics, no gradient buffers):
+ * One whole BPR-MF optimisation step, pull-based (no float atomics, no global integer atomics,
+ * no gradient buffers):
  *   reference trainers/mf_trainer.py:106-112 = 2 x forward + BPRLoss + loss.backward()
  *   + torch.optim.Adam/AdamW.step() (trainers/base_trainer.py:34-38), dense semantics
- *   (every row of both tables is updated, rows without contributions with grad = 0).
- * Sequence enqueued on `stream`: two-level counting sort of the batch by user and by item
- * (level 1: buckets of 64 rows, LDS histograms + one global integer atomic per workgroup and
- * bucket; level 2: LDS counting sort inside each bucket), a fused pass over the user rows
- * (scores, loss, user gradient in registers, Adam -> U_new; one coefficient per triplet for
- * the item side), a gather of the coefficients into item order, a fused pass over the item
- * rows (item gradient from the OLD user rows, Adam in place).  See csrc/bpr_pull.hip.  Limits: num_users, num_items < 2^24.
+ *   (every row of both tables is updated, rows without contributions with grad = 0), and the
+ *   `train_loss += loss.item()` of mf_trainer.py:114 without the host sync.
+ * THREE launches on `stream` (csrc/bpr_pull.hip): a tile partition of the batch (every tile of
+ * 1024..8192 triplets is counting-sorted in LDS by destination bucket of 1024/D rows, once by
+ * user and once by item, into the tile's own region of the record arrays), an owner pass over the
+ * user buckets (the owner workgroup of a bucket reads its segment of every tile, sorts it by row in
+ * LDS and walks the sorted stream: scores, loss, user gradient in registers, Adam -> U_new; one
+ * coefficient per triplet for the item side) and an owner pass over the item buckets (item gradient from the OLD user
+ * rows, Adam in place; its first workgroup also reduces the loss partials in fixed order).
+ * Limits: rows / (1024/D) <= 16383 buckets per table, num_users < 2^26 (YR_ERR_UNSUPPORTED beyond).
  *
  *   U_old  [num_users, D]  read;  U_new [num_users, D] written (must not alias U_old:
  *          the caller ping-pongs the two buffers between steps);
@@ -117,43 +121,48 @@ int yr_bpr_mf_fwd_bwd(const float *U, const float *I,
  *          [num_items, D] there INSTEAD of applying Adam (mI/vI/I untouched): the caller
  *          all-reduces it across ranks and applies yr_adam_dense (user-sharded multi-GPU);
  *   inv_batch: 1 / (global batch size); loss_partials as for yr_bpr_mf_fwd_bwd;
+ *   loss_out (float[1]) / loss_accum (double[1]), either may be NULL: the step's mean loss
+ *          (sum of partials x inv_batch) is stored / added there by the item pass;
  *   lr..weight_decay, step_size, bc2_sqrt, mode: as for yr_adam_dense;
- *   heavy_threshold: rows with more contributions than this are summed by a whole
- *          256-thread workgroup instead of one wave (<= 0: default 256);
- *   workspace: >= yr_bpr_mf_pull_workspace_bytes(B, num_users, num_items) bytes, 16-byte
- *          aligned, contents irrelevant on entry.
+ *   workspace: >= yr_bpr_mf_pull_workspace_bytes(B, num_users, num_items, D) bytes, 16-byte
+ *          aligned, contents irrelevant on entry (a size computed for max_batch serves every
+ *          B <= max_batch).
  * ------------------------------------------------------------------------- */
-int64_t yr_bpr_mf_pull_workspace_bytes(int64_t max_batch, int64_t num_users, int64_t num_items);
+int64_t yr_bpr_mf_pull_workspace_bytes(int64_t max_batch, int64_t num_users, int64_t num_items, int D);
 int yr_bpr_mf_pull_step(const float *U_old, float *U_new, float *I,
                         float *mU, float *vU, float *mI, float *vI, float *gradI_out,
                         const int64_t *user, const int64_t *pos, const int64_t *neg,
                         int64_t B, int D, int64_t num_users, int64_t num_items, float inv_batch,
                         double lr, double step_size, double bc2_sqrt,
                         double beta1, double beta2, double eps, double weight_decay, int mode,
-                        int heavy_threshold, void *workspace, int64_t workspace_bytes,
-                        float *loss_partials, int32_t *err_flag, void *stream);
+                        void *workspace, int64_t workspace_bytes,
+                        float *loss_partials, float *loss_out, double *loss_accum,
+                        int32_t *err_flag, void *stream);
 
 /* The same step in two phases, for callers that overlap work:
- *   yr_bpr_mf_pull_index  builds the batch index (the two-level counting sort) into `workspace`; it
- *                         depends only on the triplets, so it may be enqueued for batch k+1 while
- *                         the all-reduce of batch k is in flight (use a second workspace);
- *   yr_bpr_mf_pull_apply  runs the fused user pass / item pass on an index built for the same
- *                         B, num_users, num_items in the same workspace.  `phases` selects
+ *   yr_bpr_mf_pull_index  partitions the batch (launch 1) into `workspace`; it depends only on the
+ *                         triplets, so it may be enqueued for batch k+1 while the all-reduce of
+ *                         batch k is in flight (use a second workspace);
+ *   yr_bpr_mf_pull_apply  runs the owner passes on a partition built for the same B, D,
+ *                         num_users, num_items in the same workspace.  `phases` selects
  *                         YR_PULL_USER_PHASE and/or YR_PULL_ITEM_PHASE; the item phase covers item
  *                         rows [item_row_begin, item_row_end) only, so the item gradient can be
- *                         produced (and all-reduced) in chunks.  The user phase must have run for
- *                         the batch before any item phase.
+ *                         produced (and all-reduced) in chunks; both bounds must be multiples of
+ *                         the bucket size 1024/D (item_row_end may also equal num_items).  The user
+ *                         phase must have run for the batch before any item phase; the loss is
+ *                         finalized by the call that runs the user phase.
  * yr_bpr_mf_pull_step == index, then apply with both phases over all item rows.             */
-int yr_bpr_mf_pull_index(const int64_t *user, const int64_t *pos, const int64_t *neg, int64_t B,
-                         int64_t num_users, int64_t num_items, int heavy_threshold,
+int yr_bpr_mf_pull_index(const int64_t *user, const int64_t *pos, const int64_t *neg, int64_t B, int D,
+                         int64_t num_users, int64_t num_items,
                          void *workspace, int64_t workspace_bytes, int32_t *err_flag, void *stream);
 int yr_bpr_mf_pull_apply(const float *U_old, float *U_new, float *I,
                          float *mU, float *vU, float *mI, float *vI, float *gradI_out,
                          int64_t B, int D, int64_t num_users, int64_t num_items, float inv_batch,
                          double lr, double step_size, double bc2_sqrt,
                          double beta1, double beta2, double eps, double weight_decay, int mode,
-                         int heavy_threshold, void *workspace, int64_t workspace_bytes,
-                         float *loss_partials, int phases, int64_t item_row_begin, int64_t item_row_end,
+                         void *workspace, int64_t workspace_bytes,
+                         float *loss_partials, float *loss_out, double *loss_accum,
+                         int phases, int64_t item_row_begin, int64_t item_row_end,
                          void *stream);
 
 /* ---------------------------------------------------------------------------

@@ -45,9 +45,13 @@ def test_argument_checks_without_gpu():
     """Entry points reject bad arguments before touching the device."""
     from yelprecommendation_amd import _lib
     lib = _lib.load()
-    assert lib.yr_bpr_mf_pull_workspace_bytes(-1, 10, 10) == -2
-    n = lib.yr_bpr_mf_pull_workspace_bytes(1 << 20, 31668, 38048)
-    assert 50e6 < n < 120e6                      # ~72 B per triplet + per-row tables
+    assert lib.yr_bpr_mf_pull_workspace_bytes(-1, 10, 10, 64) == -2
+    assert lib.yr_bpr_mf_pull_workspace_bytes(10, 10, 10, 48) == -1
+    n = lib.yr_bpr_mf_pull_workspace_bytes(1 << 20, 31668, 38048, 64)
+    assert 36e6 < n < 45e6                       # 36 B per triplet + per-tile bucket offsets
+    # a size computed for max_batch serves every smaller batch (the tiling depends on B)
+    for b in (0, 1, 1000, 1 << 15, (1 << 15) + 1, 65536, 200000, (1 << 20) - 1):
+        assert lib.yr_bpr_mf_pull_workspace_bytes(b, 31668, 38048, 64) <= n
     assert lib.yr_adam_dense(None, None, None, None, 16, 1e-3, 1e-3, 1.0, 0.9, 0.999, 1e-8, 0.0, 0, 0, None) == -2
     assert lib.yr_adam_dense(None, None, None, None, 0, 1e-3, 1e-3, 1.0, 0.9, 0.999, 1e-8, 0.0, 0, 0, None) == 0
     assert lib.yr_topk_masked(None, 1, 10, 10, None, None, None, 0.0, 100, None, None) == -2   # k > 64

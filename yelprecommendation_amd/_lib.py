@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
-ENGINE_VERSION = 18
+ENGINE_VERSION = 19
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -28,9 +28,9 @@ SIGNATURES = {
     "yr_mf_score": [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _p],
     "yr_mf_score_backward": [_p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _p, _p],
     "yr_bpr_mf_fwd_bwd": [_p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _f, _p, _p, _p, _p, _p],
-    "yr_bpr_mf_pull_workspace_bytes": [_i64, _i64, _i64],
+    "yr_bpr_mf_pull_workspace_bytes": [_i64, _i64, _i64, _int],
     "yr_bpr_mf_pull_step": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _f,
-                            _d, _d, _d, _d, _d, _d, _d, _int, _int, _p, _i64, _p, _p, _p],
+                            _d, _d, _d, _d, _d, _d, _d, _int, _p, _i64, _p, _p, _p, _p, _p],
     "yr_spmm_csr": [_p, _p, _p, _p, _p, _i64, _int, _int, _p, _i64, _int, _p],
     "yr_ngcf_score_fwd": [_p, _int, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _p, _p],
     "yr_ngcf_score_bwd": [_p, _p, _int, _p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p],
@@ -47,9 +47,9 @@ SIGNATURES = {
     "yr_row_scatter_add": [_p, _p, _i64, _int, _i64, _p, _p],
     "yr_nsbce_fwd": [_p, _p, _p, _i64, _p, _p, _p],
     "yr_nsbce_bwd": [_p, _p, _p, _p, _p, _i64, _p, _p],
-    "yr_bpr_mf_pull_index": [_p, _p, _p, _i64, _i64, _i64, _int, _p, _i64, _p, _p],
+    "yr_bpr_mf_pull_index": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _p, _p],
     "yr_bpr_mf_pull_apply": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _f,
-                             _d, _d, _d, _d, _d, _d, _d, _int, _int, _p, _i64, _p, _int, _i64, _i64, _p],
+                             _d, _d, _d, _d, _d, _d, _d, _int, _p, _i64, _p, _p, _p, _int, _i64, _i64, _p],
     "yr_loss_finalize": [_p, _f, _p, _p, _p],
     "yr_mf_scores_gemm": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _p, _p],
     "yr_mf_eval_topk_workspace_bytes": [_i64, _i64, _int],

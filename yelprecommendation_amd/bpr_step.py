@@ -10,10 +10,11 @@ equal — to float rounding — to the reference's per-batch sequence
 The running loss stays on the device.
 
 Two implementations of the same step:
-  impl="pull"   (default) csrc/bpr_pull.hip: two-level counting sort of the batch by user and
-                by item, then one fused pass per table in which each row pulls its contributions
-                into registers and applies Adam — no float atomics, no gradient buffers.  The user table is
-                double-buffered; ``self.U`` is always the current one.
+  impl="pull"   (default) csrc/bpr_pull.hip, three launches: tile partition of the batch by
+                destination bucket, then one owner pass per table in which each row pulls its
+                contributions into registers and applies Adam — no float atomics, no global integer
+                atomics, no gradient buffers; the loss is reduced by the last launch.  The user
+                table is double-buffered; ``self.U`` is always the current one.
   impl="atomic" csrc/bpr_mf.hip + csrc/optim.hip: scatter-add with float atomics into dense
                 gradient buffers, then two dense Adam launches.
 """
@@ -23,13 +24,14 @@ from . import engine
 from .user_shard import sharded_item_exchange
 
 
-# below this many triplets per step the float-atomic form wins (3 launches instead of 8; the
-# atomic ceiling only bites at large batches) — measured crossover ~100 k on MI355X
-AUTO_PULL_MIN_BATCH = 114688   # measured crossover at Yelp2018 shape (atomic 96 us vs pull 100 us at 98,304; 116 vs 102 us at 131,072)
+# impl="auto": the pull form from this many triplets per rank and step upwards (0: always — its three
+# launches undercut the atomic form's four at every batch size measured); the choice is made
+# from the GLOBAL batch so that every rank of a sharded run takes the same form
+AUTO_PULL_MIN_BATCH = 0
 
 IMPL_NAMES = {
-    "auto": "auto: atomic scatter below %d triplets per step, pull above" % AUTO_PULL_MIN_BATCH,
-    "pull": "pull: 2-level counting sort + fused per-row gather/score/loss/grad/Adam (no float atomics)",
+    "auto": "auto: pull (atomic scatter only where the pull form does not support the table shape)",
+    "pull": "pull: tile partition + owner pass per table (gather/score/loss/grad/Adam fused, no atomics)",
     "atomic": "atomic: fused gather/score/loss + float-atomic scatter-add, dense Adam",
 }
 
@@ -37,7 +39,7 @@ IMPL_NAMES = {
 class BPRMFStep:
     def __init__(self, U, I, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, optimizer="adam",
                  world_size=1, process_group=None, time_kernels=False, impl="auto", max_batch=0,
-                 heavy_threshold=0, state=None, split_item_update=False, item_chunks=2):
+                 state=None, split_item_update=False, item_chunks=2):
         """``state``: optional dict with pre-existing Adam tensors ``mU, vU, mI, vI`` (shared, updated
         in place) and the step count ``t`` — lets a trainer keep its torch-style optimizer state
         in sync with the fused step (see MFTrainer).
@@ -53,7 +55,6 @@ class BPRMFStep:
             raise ValueError(f"impl must be one of {list(IMPL_NAMES)}")
         self.impl_key, self.impl = impl, IMPL_NAMES[impl]
         self.launches = ""
-        self.heavy_threshold = heavy_threshold
         self.U, self.I = U, I
         self._U_alt = None
         self._ws_slots, self._ws_batch, self._indexed = [None, None], [0, 0], None
@@ -94,6 +95,9 @@ class BPRMFStep:
         self._pI, self._pmU, self._pvU = I.data_ptr(), self.mU.data_ptr(), self.vU.data_ptr()
         self._pmI, self._pvI = self.mI.data_ptr(), self.vI.data_ptr()
         self._ppartials, self._pflag = self.partials.data_ptr(), self.flag.data_ptr()
+        # table shapes the pull form does not cover (very many rows) fall back to the atomic form under "auto"
+        self._pull_ok = self._lib.yr_bpr_mf_pull_workspace_bytes(1, U.shape[0], I.shape[0], U.shape[1]) > 0 and \
+            engine.pull_supported(U.shape[0], I.shape[0], U.shape[1])
 
     # -- timing of individual kernels with events on the launch stream ------------------------
     def reset_timers(self):
@@ -119,7 +123,8 @@ class BPRMFStep:
         batch k's all-reduce is in flight."""
         ws = self._ws_slots[slot]
         if ws is None or batch > self._ws_batch[slot]:
-            ws = engine.bpr_mf_pull_workspace(batch, self.U.shape[0], self.I.shape[0], self.U.device)
+            ws = engine.bpr_mf_pull_workspace(batch, self.U.shape[0], self.I.shape[0], self.U.shape[1],
+                                              self.U.device)
             self._ws_slots[slot], self._ws_batch[slot] = ws, batch
         return ws
 
@@ -134,13 +139,14 @@ class BPRMFStep:
             global_batch = u.numel() * self.world_size
         key = self.impl_key
         if key == "auto":
-            key = "pull" if u.numel() >= AUTO_PULL_MIN_BATCH else "atomic"
+            # decided from quantities that are equal on every rank (the two forms issue different
+            # collectives): global batch and the table shapes
+            key = "pull" if (global_batch >= AUTO_PULL_MIN_BATCH * self.world_size and self._pull_ok) else "atomic"
         if key == "pull":
             if self._U_alt is None:
                 self._U_alt = torch.empty_like(self.U)
             self.impl = IMPL_NAMES["pull"]
-            self.launches = ("part_count, part_scan, part_scatter, bucket_sort, pull_rows<user>, permute_coeff, "
-                             "pull_rows<item>")
+            self.launches = "tile_partition, owner_pass<user>, owner_pass<item>"
             return self._step_pull(u, p, n, record, global_batch, next_batch)
         if self.gU is None:
             self.gU = torch.zeros_like(self.U)
@@ -160,8 +166,8 @@ class BPRMFStep:
     def _build_index(self, u, p, n, slot):
         B = self._check_triplets(u, p, n)
         ws = self._workspace(B, slot)
-        rc = self._lib.yr_bpr_mf_pull_index(u.data_ptr(), p.data_ptr(), n.data_ptr(), B, self.U.shape[0],
-                                            self.I.shape[0], self.heavy_threshold, ws.data_ptr(), ws.numel(),
+        rc = self._lib.yr_bpr_mf_pull_index(u.data_ptr(), p.data_ptr(), n.data_ptr(), B, self.U.shape[1],
+                                            self.U.shape[0], self.I.shape[0], ws.data_ptr(), ws.numel(),
                                             self._pflag, engine._stream())
         if rc:
             engine.check(rc, "yr_bpr_mf_pull_index")
@@ -183,19 +189,22 @@ class BPRMFStep:
 
         nchunks = self.item_chunks if multi else 1
         rows = self.I.shape[0]
-        bounds = [rows * c // nchunks for c in range(nchunks + 1)]
+        gran = engine.pull_bucket_rows(D)           # item chunks are whole owner buckets
+        bounds = [min(rows, (rows * c // nchunks + gran - 1) // gran * gran) for c in range(nchunks)] + [rows]
         both = engine.PULL_USER_PHASE | engine.PULL_ITEM_PHASE
+        ploss, paccum = self.loss.data_ptr(), self.loss_accum.data_ptr()
 
         def apply(phases, r0, r1):
             ws = self._ws_slots[slot]
+            with_loss = bool(phases & engine.PULL_USER_PHASE)   # that call's last launch reduces the loss
             step_size, bc2_sqrt = engine.adam_scalars(self.t, self.lr, self.betas[0], self.betas[1])
             rc = self._lib.yr_bpr_mf_pull_apply(
                 self.U.data_ptr(), self._U_alt.data_ptr(), self._pI, self._pmU, self._pvU, self._pmI, self._pvI,
                 self.gI.data_ptr() if multi else None, B, D, self.U.shape[0], rows, inv, self.lr,
                 step_size, bc2_sqrt, self.betas[0], self.betas[1], self.eps, self.wd,
-                engine.OPT_ADAMW if self.decoupled else engine.OPT_ADAM, self.heavy_threshold,
-                ws.data_ptr(), ws.numel(), self._ppartials, phases, r0, r1,
-                engine._stream())
+                engine.OPT_ADAMW if self.decoupled else engine.OPT_ADAM,
+                ws.data_ptr(), ws.numel(), self._ppartials, ploss if with_loss else None,
+                paccum if with_loss else None, phases, r0, r1, engine._stream())
             if rc:
                 engine.check(rc, "yr_bpr_mf_pull_apply")
 
@@ -237,10 +246,6 @@ class BPRMFStep:
                               overlap)
         self._gI_dirty = multi
         self.U, self._U_alt = self._U_alt, self.U
-        rc = self._lib.yr_loss_finalize(self._ppartials, inv, self.loss.data_ptr(), self.loss_accum.data_ptr(),
-                                        engine._stream())
-        if rc:
-            engine.check(rc, "yr_loss_finalize")
 
     def _step_atomic(self, u, p, n, record, global_batch):
         B = self._check_triplets(u, p, n)

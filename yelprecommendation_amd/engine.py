@@ -118,10 +118,28 @@ def bpr_mf_fwd_bwd(U, I, user, pos, neg, gradU, gradI, loss_partials, inv_batch=
                                 _opt(err_flag, torch.int32, "err_flag"), _stream()), "yr_bpr_mf_fwd_bwd")
 
 
-def bpr_mf_pull_workspace(max_batch, num_users, num_items, device):
+PULL_MAX_BUCKETS = 16383      # csrc/bpr_pull.hip kMaxBuckets
+PULL_MAX_USERS = (1 << 26) - 1
+
+
+def pull_bucket_rows(d):
+    """Rows per owner bucket of the pull step (1024 / D): the granularity of item-row chunks."""
+    return 1024 // int(d)
+
+
+def pull_supported(num_users, num_items, d):
+    """Table shapes the pull step covers (include/yelprec_engine.h, limits of yr_bpr_mf_pull_step)."""
+    if d not in SUPPORTED_WIDTHS:
+        return False
+    r = pull_bucket_rows(d)
+    return (-(-num_users // r) <= PULL_MAX_BUCKETS and -(-num_items // r) <= PULL_MAX_BUCKETS
+            and num_users <= PULL_MAX_USERS)
+
+
+def bpr_mf_pull_workspace(max_batch, num_users, num_items, d, device):
     """Scratch buffer for :func:`bpr_mf_pull_step` (uint8 tensor, 256-byte aligned by torch)."""
     lib = _lib.load()
-    n = lib.yr_bpr_mf_pull_workspace_bytes(int(max_batch), int(num_users), int(num_items))
+    n = lib.yr_bpr_mf_pull_workspace_bytes(int(max_batch), int(num_users), int(num_items), int(d))
     if n < 0:
         check(int(n), "yr_bpr_mf_pull_workspace_bytes")
     return torch.empty(int(n), dtype=torch.uint8, device=device)
@@ -129,7 +147,7 @@ def bpr_mf_pull_workspace(max_batch, num_users, num_items, device):
 
 def bpr_mf_pull_step(U_old, U_new, I, mU, vU, mI, vI, user, pos, neg, step, lr, loss_partials, workspace,
                      beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, decoupled=False, inv_batch=None,
-                     gradI_out=None, heavy_threshold=0, err_flag=None):
+                     gradI_out=None, err_flag=None, loss_out=None, loss_accum=None):
     """One whole BPR-MF step (forward, loss, both gradients, dense Adam) without float atomics.
 
     reference trainers/mf_trainer.py:106-112.  Reads ``U_old``, writes ``U_new`` (distinct
@@ -155,9 +173,10 @@ def bpr_mf_pull_step(U_old, U_new, I, mU, vU, mI, vI, user, pos, neg, step, lr, 
         _opt(gradI_out, f32, "gradI_out"),
         _dev(user, torch.int64, "user"), _dev(pos, torch.int64, "pos"), _dev(neg, torch.int64, "neg"),
         B, d, nu, ni, float(inv_batch), float(lr), float(step_size), float(bc2_sqrt), float(beta1), float(beta2),
-        float(eps), float(weight_decay), OPT_ADAMW if decoupled else OPT_ADAM, int(heavy_threshold),
+        float(eps), float(weight_decay), OPT_ADAMW if decoupled else OPT_ADAM,
         _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
-        _dev(loss_partials, f32, "loss_partials"), _opt(err_flag, torch.int32, "err_flag"), _stream()),
+        _dev(loss_partials, f32, "loss_partials"), _opt(loss_out, f32, "loss_out"),
+        _opt(loss_accum, torch.float64, "loss_accum"), _opt(err_flag, torch.int32, "err_flag"), _stream()),
         "yr_bpr_mf_pull_step")
 
 
