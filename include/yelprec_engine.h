@@ -99,6 +99,34 @@ int yr_bpr_mf_fwd_bwd(const float *U, const float *I,
                       float *loss_partials, int32_t *err_flag, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * The whole step for SMALL batches in two launches (the pull form below wins from a few
+ * thousand triplets upwards): yr_bpr_mf_fwd_bwd's scatter, marking the rows it touches in
+ * `touched` (uint8[num_users + num_items], all zero on entry and again on exit; may be NULL),
+ * then yr_adam_dense_dual: dense Adam/AdamW over BOTH tables in one launch that reads / clears a
+ * gradient row only where it was marked (every row still gets its update: dense semantics of
+ * trainers/base_trainer.py:34-38) and reduces the loss partials into loss_out / loss_accum
+ * (mf_trainer.py:114 without the host sync).  gradU / gradI: dense, zero on entry and on exit.
+ * yr_adam_dense_dual on its own: p0/p1 any two tensors with n0/n1 elements (multiples of 4),
+ * touched0/touched1 per row of `row_width` elements or NULL (gradient always read and cleared),
+ * loss_partials NULL = no loss reduction.
+ * ------------------------------------------------------------------------- */
+int yr_bpr_mf_scatter_step(float *U, float *I, float *gradU, float *gradI,
+                           float *mU, float *vU, float *mI, float *vI, uint8_t *touched,
+                           const int64_t *user, const int64_t *pos, const int64_t *neg,
+                           int64_t B, int D, int64_t num_users, int64_t num_items, float inv_batch,
+                           double lr, double step_size, double bc2_sqrt,
+                           double beta1, double beta2, double eps, double weight_decay, int mode,
+                           float *loss_partials, float *loss_out, double *loss_accum,
+                           int32_t *err_flag, void *stream);
+int yr_adam_dense_dual(float *p0, float *g0, float *m0, float *v0, int64_t n0,
+                       float *p1, float *g1, float *m1, float *v1, int64_t n1,
+                       int row_width, uint8_t *touched0, uint8_t *touched1,
+                       double lr, double step_size, double bc2_sqrt,
+                       double beta1, double beta2, double eps, double weight_decay, int mode,
+                       const float *loss_partials, float loss_scale, float *loss_out, double *loss_accum,
+                       void *stream);
+
+/* ---------------------------------------------------------------------------
  * One whole BPR-MF optimisation step, pull-based (no float atomics, no global integer atomics,
  * no gradient buffers):
  *   reference trainers/mf_trainer.py:106-112 = 2 x forward + BPRLoss + loss.backward()

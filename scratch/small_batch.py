@@ -1,4 +1,4 @@
-"""Step time across batch sizes at Yelp2018 shape: python scratch/small_batch.py [impl] [sizes...]"""
+"""Step time across batch sizes at Yelp2018 shape (uniform ids): python scratch/small_batch.py [impl] [sizes...]"""
 import sys, time, torch
 sys.path.insert(0, '.')
 from yelprecommendation_amd.bpr_step import BPRMFStep
@@ -10,7 +10,7 @@ U = torch.randn(nu, d, device=dev) * 0.05; I = torch.randn(ni, d, device=dev) * 
 step = BPRMFStep(U, I, lr=1e-4, impl=impl)
 for B in sizes:
     u = torch.randint(0, nu, (B,), device=dev)
-    p = (torch.rand(B, device=dev).pow(3) * ni).long().clamp_(max=ni - 1)      # popularity-skewed positives
+    p = torch.randint(0, ni, (B,), device=dev)
     n = torch.randint(0, ni, (B,), device=dev)
     for _ in range(20): step.step(u, p, n)
     torch.cuda.synchronize(); t = time.perf_counter()

@@ -28,6 +28,10 @@ SIGNATURES = {
     "yr_mf_score": [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _p],
     "yr_mf_score_backward": [_p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _p, _p],
     "yr_bpr_mf_fwd_bwd": [_p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _f, _p, _p, _p, _p, _p],
+    "yr_bpr_mf_scatter_step": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _f,
+                               _d, _d, _d, _d, _d, _d, _d, _int, _p, _p, _p, _p, _p],
+    "yr_adam_dense_dual": [_p, _p, _p, _p, _i64, _p, _p, _p, _p, _i64, _int, _p, _p,
+                           _d, _d, _d, _d, _d, _d, _d, _int, _p, _f, _p, _p, _p],
     "yr_bpr_mf_pull_workspace_bytes": [_i64, _i64, _i64, _int],
     "yr_bpr_mf_pull_step": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _f,
                             _d, _d, _d, _d, _d, _d, _d, _int, _p, _i64, _p, _p, _p, _p, _p],

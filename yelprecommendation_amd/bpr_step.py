@@ -15,8 +15,9 @@ Two implementations of the same step:
                 contributions into registers and applies Adam — no float atomics, no global integer
                 atomics, no gradient buffers; the loss is reduced by the last launch.  The user
                 table is double-buffered; ``self.U`` is always the current one.
-  impl="atomic" csrc/bpr_mf.hip + csrc/optim.hip: scatter-add with float atomics into dense
-                gradient buffers, then two dense Adam launches.
+  impl="atomic" csrc/bpr_mf.hip + csrc/optim.hip, two launches: scatter-add with float atomics into
+                dense gradient buffers (marking the rows it touches), then ONE dense Adam pass over both
+                tables that also reduces the loss.
 """
 import torch
 
@@ -24,13 +25,14 @@ from . import engine
 from .user_shard import sharded_item_exchange
 
 
-# impl="auto": the pull form from this many triplets per rank and step upwards (0: always — its three
-# launches undercut the atomic form's four at every batch size measured); the choice is made
-# from the GLOBAL batch so that every rank of a sharded run takes the same form
-AUTO_PULL_MIN_BATCH = 0
+# impl="auto": the pull form from this many triplets per rank and step upwards, the two-launch atomic
+# form below (measured on MI355X at Yelp2018 shape: 24 vs 39 us at 4,096, 34 vs 42 us at 16,384, 45.7 vs
+# 45.3 us at 32,768, 68 vs 53 us at 65,536); the choice is made from the GLOBAL batch so that every rank
+# of a sharded run takes the same form (the two forms issue different collectives)
+AUTO_PULL_MIN_BATCH = 32768
 
 IMPL_NAMES = {
-    "auto": "auto: pull (atomic scatter only where the pull form does not support the table shape)",
+    "auto": "auto: atomic scatter + one Adam launch below %d triplets per rank and step, pull above" % AUTO_PULL_MIN_BATCH,
     "pull": "pull: tile partition + owner pass per table (gather/score/loss/grad/Adam fused, no atomics)",
     "atomic": "atomic: fused gather/score/loss + float-atomic scatter-add, dense Adam",
 }
@@ -61,6 +63,7 @@ class BPRMFStep:
         if impl == "pull" and max_batch:
             self._workspace(max_batch, 0)
         self._gI_dirty = False
+        self._touched = None
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.decoupled = optimizer.lower() == "adamw"
         self.world_size, self.pg = world_size, process_group
@@ -153,7 +156,7 @@ class BPRMFStep:
         if self.gI is None:
             self.gI = torch.zeros_like(self.I)
         self.impl = IMPL_NAMES["atomic"]
-        self.launches = "bpr_fwd_bwd, adam_dense x2"
+        self.launches = "bpr_fwd_bwd, adam_dual"
         return self._step_atomic(u, p, n, record, global_batch)
 
     def _check_triplets(self, u, p, n):
@@ -257,6 +260,26 @@ class BPRMFStep:
             self._gI_dirty = False
         nU, nI = self.U.shape[0], self.I.shape[0]
         pU, pgU, pgI = self.U.data_ptr(), self.gU.data_ptr(), self.gI.data_ptr()
+        self.t += 1
+        step_size, bc2_sqrt = engine.adam_scalars(self.t, self.lr, self.betas[0], self.betas[1])
+        mode = engine.OPT_ADAMW if self.decoupled else engine.OPT_ADAM
+        ploss, paccum = self.loss.data_ptr(), self.loss_accum.data_ptr()
+        if self.world_size == 1:
+            # two launches: scatter (marks the rows it touches) + Adam over both tables with the loss reduction
+            if self._touched is None:
+                self._touched = torch.zeros(nU + nI, dtype=torch.uint8, device=self.U.device)
+
+            def whole():
+                rc = lib.yr_bpr_mf_scatter_step(pU, self._pI, pgU, pgI, self._pmU, self._pvU, self._pmI, self._pvI,
+                                                self._touched.data_ptr(), u.data_ptr(), p.data_ptr(), n.data_ptr(),
+                                                B, D, nU, nI, inv, self.lr, step_size, bc2_sqrt, self.betas[0],
+                                                self.betas[1], self.eps, self.wd, mode, self._ppartials, ploss,
+                                                paccum, self._pflag, stream)
+                if rc:
+                    engine.check(rc, "yr_bpr_mf_scatter_step")
+
+            self._timed("bpr_scatter_step", B * (24 + 24 * D) + 6 * 4 * (nU + nI) * D, record, whole)
+            return
 
         def fwd_bwd():
             rc = lib.yr_bpr_mf_fwd_bwd(pU, self._pI, u.data_ptr(), p.data_ptr(), n.data_ptr(), B, D, nU, nI, inv,
@@ -265,27 +288,18 @@ class BPRMFStep:
                 engine.check(rc, "yr_bpr_mf_fwd_bwd")
 
         self._timed("bpr_fwd_bwd", B * (24 + 24 * D), record, fwd_bwd)
-        work = None
-        if self.world_size > 1:
-            import torch.distributed as dist
-            work = dist.all_reduce(self.gI, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        rc = lib.yr_loss_finalize(self._ppartials, inv, self.loss.data_ptr(), self.loss_accum.data_ptr(), stream)
-        if rc:
-            engine.check(rc, "yr_loss_finalize")
-        self.t += 1
-        step_size, bc2_sqrt = engine.adam_scalars(self.t, self.lr, self.betas[0], self.betas[1])
-        mode = engine.OPT_ADAMW if self.decoupled else engine.OPT_ADAM
+        import torch.distributed as dist
+        dist.all_reduce(self.gI, op=dist.ReduceOp.SUM, group=self.pg)
 
-        def adam(ptr, g, m, v, count):
-            rc = lib.yr_adam_dense(ptr, g, m, v, count, self.lr, step_size, bc2_sqrt, self.betas[0], self.betas[1],
-                                   self.eps, self.wd, mode, 1, stream)
+        def adam():
+            rc = lib.yr_adam_dense_dual(pU, pgU, self._pmU, self._pvU, nU * D, self._pI, pgI, self._pmI, self._pvI,
+                                        nI * D, D, None, None, self.lr, step_size, bc2_sqrt, self.betas[0],
+                                        self.betas[1], self.eps, self.wd, mode, self._ppartials, inv, ploss, paccum,
+                                        stream)
             if rc:
-                engine.check(rc, "yr_adam_dense")
+                engine.check(rc, "yr_adam_dense_dual")
 
-        self._timed("adam_dense_user", 8 * 4 * nU * D, record, lambda: adam(pU, pgU, self._pmU, self._pvU, nU * D))
-        if work is not None:
-            work.wait()
-        self._timed("adam_dense_item", 8 * 4 * nI * D, record, lambda: adam(self._pI, pgI, self._pmI, self._pvI, nI * D))
+        self._timed("adam_dense_dual", 8 * 4 * (nU + nI) * D, record, adam)
 
     def epoch_loss(self, reset=True):
         """Sum of per-batch mean losses since the last reset (one host sync).  At N > 1 the

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_bwd_kernel(
     const int64_t* __restrict__ user, const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
     int64_t B, int64_t num_users, int64_t num_items, float inv_batch,
     float* __restrict__ gradU, float* __restrict__ gradI,
-    float* __restrict__ loss_partials, int32_t* __restrict__ err_flag) {
+    float* __restrict__ loss_partials, int32_t* __restrict__ err_flag, uint8_t* __restrict__ touched) {
   using G = RowGeom<D>;
   constexpr int PER_WAVE = TILE / kWavesPerBlock;
   __shared__ int32_t s_idx[3][TILE];
@@ -136,6 +136,11 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_bwd_kernel(
               atomicAdd(du + j * kWave, g * diff[j]);
               atomicAdd(dp + j * kWave, gu);
               atomicAdd(dn + j * kWave, -gu);
+            }
+            if (touched && l == 0) {              // rows whose gradient is not zero: [users | items]
+              touched[uu[q]] = 1;
+              touched[num_users + pp[q]] = 1;
+              touched[num_users + nn[q]] = 1;
             }
           }
         }
@@ -305,10 +310,9 @@ extern "C" int yr_mf_score_backward(const float* U, const float* I, const int64_
   return launch_status();
 }
 
-extern "C" int yr_bpr_mf_fwd_bwd(const float* U, const float* I, const int64_t* user, const int64_t* pos,
-                                 const int64_t* neg, int64_t B, int D, int64_t num_users, int64_t num_items,
-                                 float inv_batch, float* gradU, float* gradI, float* loss_partials,
-                                 int32_t* err_flag, void* stream) {
+static int fwd_bwd_launch(const float* U, const float* I, const int64_t* user, const int64_t* pos, const int64_t* neg,
+                          int64_t B, int D, int64_t num_users, int64_t num_items, float inv_batch, float* gradU,
+                          float* gradI, float* loss_partials, int32_t* err_flag, uint8_t* touched, void* stream) {
   if (B < 0 || num_users <= 0 || num_items <= 0 || !loss_partials) return YR_ERR_BADARG;
   if ((gradU == nullptr) != (gradI == nullptr)) return YR_ERR_BADARG;
   hipStream_t s = (hipStream_t)stream;
@@ -318,19 +322,57 @@ extern "C" int yr_bpr_mf_fwd_bwd(const float* U, const float* I, const int64_t* 
     return launch_status();
   }
   if (!U || !I || !user || !pos || !neg) return YR_ERR_BADARG;
-  const bool small = B <= 131072;                      // 64-triplet tiles: enough workgroups for every CU (measured: 32k 77 -> 51 us, 64k 80 -> 73 us)
-  const int grid = grid_for(B, small ? 64 : kTile);
+  // triplets staged per workgroup: 256 for throughput; 64 up to 131,072 triplets so that every CU gets
+  // workgroups (measured: 32k 77 -> 51 us, 64k 80 -> 73 us); 16 up to 16,384 — a wave then makes ONE pass
+  // of four triplets instead of four passes in a row (a 32-triplet step waited 10 us for those round trips)
+  const int tile = B <= 16384 ? 16 : B <= 131072 ? 64 : kTile;
+  const int grid = grid_for(B, tile);
 #define YR_LAUNCH_FB(BWD, TILE)                                                                                \
   YR_DISPATCH_D(D, hipLaunchKernelGGL((bpr_fwd_bwd_kernel<kD, BWD, TILE>), dim3(grid), dim3(kBlock), 0, s, U, I, \
                                       user, pos, neg, B, num_users, num_items, inv_batch, gradU, gradI,          \
-                                      loss_partials, err_flag))
+                                      loss_partials, err_flag, touched))
   if (gradU) {
-    if (small) { YR_LAUNCH_FB(true, 64); } else { YR_LAUNCH_FB(true, kTile); }
+    if (tile == 16) { YR_LAUNCH_FB(true, 16); } else if (tile == 64) { YR_LAUNCH_FB(true, 64); } else { YR_LAUNCH_FB(true, kTile); }
   } else {
-    if (small) { YR_LAUNCH_FB(false, 64); } else { YR_LAUNCH_FB(false, kTile); }
+    if (tile == 16) { YR_LAUNCH_FB(false, 16); } else if (tile == 64) { YR_LAUNCH_FB(false, 64); } else { YR_LAUNCH_FB(false, kTile); }
   }
 #undef YR_LAUNCH_FB
   return launch_status();
+}
+
+extern "C" int yr_bpr_mf_fwd_bwd(const float* U, const float* I, const int64_t* user, const int64_t* pos,
+                                 const int64_t* neg, int64_t B, int D, int64_t num_users, int64_t num_items,
+                                 float inv_batch, float* gradU, float* gradI, float* loss_partials,
+                                 int32_t* err_flag, void* stream) {
+  return fwd_bwd_launch(U, I, user, pos, neg, B, D, num_users, num_items, inv_batch, gradU, gradI,
+                        loss_partials, err_flag, nullptr, stream);
+}
+
+// The whole step for small batches in two launches: scatter (above, marking the rows it touches) and
+// one dense Adam pass over BOTH tables that reads / clears a gradient row only where it was marked
+// and reduces the loss partials (csrc/optim.hip).
+extern "C" int yr_adam_dense_dual(float* p0, float* g0, float* m0, float* v0, int64_t n0, float* p1, float* g1,
+                                  float* m1, float* v1, int64_t n1, int row_width, uint8_t* touched0,
+                                  uint8_t* touched1, double lr, double step_size, double bc2_sqrt, double beta1,
+                                  double beta2, double eps, double weight_decay, int mode,
+                                  const float* loss_partials, float loss_scale, float* loss_out, double* loss_accum,
+                                  void* stream);
+
+extern "C" int yr_bpr_mf_scatter_step(float* U, float* I, float* gradU, float* gradI, float* mU, float* vU,
+                                      float* mI, float* vI, uint8_t* touched, const int64_t* user,
+                                      const int64_t* pos, const int64_t* neg, int64_t B, int D, int64_t num_users,
+                                      int64_t num_items, float inv_batch, double lr, double step_size,
+                                      double bc2_sqrt, double beta1, double beta2, double eps, double weight_decay,
+                                      int mode, float* loss_partials, float* loss_out, double* loss_accum,
+                                      int32_t* err_flag, void* stream) {
+  if (!gradU || !gradI || !mU || !vU || !mI || !vI || !U || !I) return YR_ERR_BADARG;
+  if (D != 16 && D != 32 && D != 64 && D != 128) return YR_ERR_UNSUPPORTED;
+  const int rc = fwd_bwd_launch(U, I, user, pos, neg, B, D, num_users, num_items, inv_batch, gradU, gradI,
+                                loss_partials, err_flag, touched, stream);
+  if (rc) return rc;
+  return yr_adam_dense_dual(U, gradU, mU, vU, num_users * D, I, gradI, mI, vI, num_items * D, D, touched,
+                            touched ? touched + num_users : nullptr, lr, step_size, bc2_sqrt, beta1, beta2, eps,
+                            weight_decay, mode, loss_partials, inv_batch, loss_out, loss_accum, stream);
 }
 
 extern "C" int yr_loss_finalize(const float* loss_partials, float scale, float* loss_out, double* loss_accum,

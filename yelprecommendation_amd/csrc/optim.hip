@@ -79,6 +79,62 @@ __global__ __launch_bounds__(kBlock) void adam_dense_multi_kernel(AdamMulti t, A
   }
 }
 
+// Two tensors in one launch (the user and the item table), 16 bytes per lane, plus the loss reduction
+// of the step: replaces two adam_dense launches and loss_finalize.  With `touched` (one byte per row
+// of `row4` float4, set by the scatter kernel) the gradient of a row is read and cleared only where
+// the batch touched it — every row still gets its Adam update (dense semantics, grad = 0).
+struct DualAdam {
+  float4 *p0, *g0, *m0, *v0, *p1, *g1, *m1, *v1;
+  uint8_t *touched0, *touched1;
+  int64_t n4_0, n4_1;
+  int row4;
+};
+
+template <bool DECOUPLED>
+__global__ __launch_bounds__(kBlock) void adam_dual_kernel(DualAdam t, AdamScalars c,
+                                                           const float* __restrict__ partials, float loss_scale,
+                                                           float* __restrict__ loss_out,
+                                                           double* __restrict__ loss_accum) {
+  const int64_t total = t.n4_0 + t.n4_1;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+    const bool second = i >= t.n4_0;
+    const int64_t j = second ? i - t.n4_0 : i;
+    float4* pp = second ? t.p1 : t.p0;
+    float4* gp = second ? t.g1 : t.g0;
+    float4* mp = second ? t.m1 : t.m0;
+    float4* vp = second ? t.v1 : t.v0;
+    uint8_t* tp = second ? t.touched1 : t.touched0;
+    float4 P = pp[j], M = mp[j], V = vp[j];
+    float4 G = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t row = tp ? j / t.row4 : 0;
+    const bool has = tp ? tp[row] != 0 : true;
+    if (has) {
+      G = gp[j];
+      gp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tp && j % t.row4 == 0) tp[row] = 0;     // after every lane of the row (same wave) has read the mark
+    }
+    adam_element<DECOUPLED>(P.x, G.x, M.x, V.x, c);
+    adam_element<DECOUPLED>(P.y, G.y, M.y, V.y, c);
+    adam_element<DECOUPLED>(P.z, G.z, M.z, V.z, c);
+    adam_element<DECOUPLED>(P.w, G.w, M.w, V.w, c);
+    pp[j] = P;
+    mp[j] = M;
+    vp[j] = V;
+  }
+  if (partials && blockIdx.x == 0) {              // fixed-order loss reduction (partials come from the previous launch)
+    __shared__ float s_red[kWavesPerBlock];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < YR_LOSS_PARTIALS; i += kBlock) s += partials[i];
+    const float tot = block_sum(s, s_red);
+    if (threadIdx.x == 0) {
+      const float v = tot * loss_scale;
+      if (loss_out) loss_out[0] = v;
+      if (loss_accum) loss_accum[0] += (double)v;
+    }
+  }
+}
+
 template <bool ZERO_GRAD>
 __global__ __launch_bounds__(kBlock) void sgd_dense_kernel(float* __restrict__ p, float* __restrict__ g,
                                                            int64_t n4, int64_t n, float lr, float wd) {
@@ -145,6 +201,47 @@ extern "C" int yr_adam_dense(float* p, float* g, float* m, float* v, int64_t n, 
     if (zero_grad) YR_LAUNCH_ADAM(false, true); else YR_LAUNCH_ADAM(false, false);
   }
 #undef YR_LAUNCH_ADAM
+  return launch_status();
+}
+
+extern "C" int yr_adam_dense_dual(float* p0, float* g0, float* m0, float* v0, int64_t n0, float* p1, float* g1,
+                                  float* m1, float* v1, int64_t n1, int row_width, uint8_t* touched0,
+                                  uint8_t* touched1, double lr, double step_size, double bc2_sqrt, double beta1,
+                                  double beta2, double eps, double weight_decay, int mode,
+                                  const float* loss_partials, float loss_scale, float* loss_out, double* loss_accum,
+                                  void* stream) {
+  if (n0 < 0 || n1 < 0 || (n0 & 3) || (n1 & 3)) return YR_ERR_BADARG;
+  if (mode != YR_OPT_ADAM && mode != YR_OPT_ADAMW) return YR_ERR_UNSUPPORTED;
+  if ((n0 > 0 && (!p0 || !g0 || !m0 || !v0)) || (n1 > 0 && (!p1 || !g1 || !m1 || !v1))) return YR_ERR_BADARG;
+  if (!aligned16(p0) || !aligned16(g0) || !aligned16(m0) || !aligned16(v0) || !aligned16(p1) || !aligned16(g1) ||
+      !aligned16(m1) || !aligned16(v1))
+    return YR_ERR_BADARG;
+  if ((touched0 || touched1) && (row_width <= 0 || (row_width & 3) || n0 % row_width || n1 % row_width))
+    return YR_ERR_BADARG;
+  DualAdam t;
+  t.p0 = (float4*)p0; t.g0 = (float4*)g0; t.m0 = (float4*)m0; t.v0 = (float4*)v0;
+  t.p1 = (float4*)p1; t.g1 = (float4*)g1; t.m1 = (float4*)m1; t.v1 = (float4*)v1;
+  t.touched0 = touched0; t.touched1 = touched1;
+  t.n4_0 = n0 / 4; t.n4_1 = n1 / 4;
+  t.row4 = row_width > 0 ? row_width / 4 : 1;
+  AdamScalars c;
+  c.decay_mul = (float)(1.0 - lr * weight_decay);
+  c.neg_step = (float)(-step_size);
+  c.bc2_sqrt = (float)bc2_sqrt;
+  c.one_m_b1 = (float)(1.0 - beta1);
+  c.beta2 = (float)beta2;
+  c.one_m_b2 = (float)(1.0 - beta2);
+  c.eps = (float)eps;
+  c.wd = (float)weight_decay;
+  const int64_t total = t.n4_0 + t.n4_1;
+  const int grid = grid_for(total > 0 ? total : 1, kBlock);
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == YR_OPT_ADAMW)
+    hipLaunchKernelGGL((adam_dual_kernel<true>), dim3(grid), dim3(kBlock), 0, s, t, c, loss_partials, loss_scale,
+                       loss_out, loss_accum);
+  else
+    hipLaunchKernelGGL((adam_dual_kernel<false>), dim3(grid), dim3(kBlock), 0, s, t, c, loss_partials, loss_scale,
+                       loss_out, loss_accum);
   return launch_status();
 }
 
