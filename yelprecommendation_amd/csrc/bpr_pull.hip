@@ -44,8 +44,6 @@
 // works on GPW = 64/LPR contributions at once; the per-contribution dot product is a reduction
 // over LPR lanes only.  At the end a wave holds GPW consecutive rows, one per lane group: own row,
 // m, v and the Adam update stream 1 KB per wave instruction.
-#include <cstdlib>
-
 #include "common.h"
 
 namespace yr {
@@ -62,11 +60,11 @@ constexpr int kMaxOwnerGrid = 4096;
 #define YR_HEAVY_ROW 96
 #endif
 #ifndef YR_ROWSUM_REGS
-#define YR_ROWSUM_REGS 4
+#define YR_ROWSUM_REGS 0             // 4: row sums of a wave's rows in registers when it owns at most four (D >= 64)
 #endif
 constexpr int kHeavyRow = YR_HEAVY_ROW;          // records per row and chunk from which all four waves share the row
 #ifndef YR_OWNER_WAVES
-#define YR_OWNER_WAVES 5              // waves per SIMD the owner pass is compiled for (5 workgroups per CU)
+#define YR_OWNER_WAVES 8              // waves per SIMD the owner pass is compiled for (8 workgroups per CU: <= 64 VGPRs)
 #endif
 
 struct AdamC {
@@ -260,7 +258,7 @@ template <int LPR, int GPW>
 struct RowSums {
   static constexpr bool kRegs = GPW <= YR_ROWSUM_REGS;
   float4 part[kRegs ? GPW : 1];
-  float4 total;                                   // generic form: running sum of this group's own row
+  float4 total;                                   // running sum of this group's own row (generic form; heavy rows)
   __device__ __forceinline__ void clear() {
 #pragma unroll
     for (int j = 0; j < (kRegs ? GPW : 1); ++j) part[j] = zero4();
@@ -289,12 +287,12 @@ struct RowSums {
   // the sum of this lane group's own row
   __device__ __forceinline__ float4 finish(int grp) {
     if (kRegs) {
-      float4 out = zero4();
+      float4 out = total;
 #pragma unroll
       for (int j = 0; j < GPW; ++j) {
         float4 t = part[j];
         cross_group_sum<LPR>(t);
-        if (grp == j) out = t;
+        if (grp == j) { out.x += t.x; out.y += t.y; out.z += t.z; out.w += t.w; }
       }
       return out;
     }
@@ -302,8 +300,14 @@ struct RowSums {
   }
 };
 
-constexpr int kUserUnroll = 2;   // steps in flight per lane group; two gathered rows per contribution
-constexpr int kItemUnroll = 4;
+#ifndef YR_USER_UNROLL
+#define YR_USER_UNROLL 1
+#endif
+#ifndef YR_ITEM_UNROLL
+#define YR_ITEM_UNROLL 2
+#endif
+constexpr int kUserUnroll = YR_USER_UNROLL;   // steps in flight per lane group; two gathered rows per contribution
+constexpr int kItemUnroll = YR_ITEM_UNROLL;
 constexpr int kTagShift = 10;    // s_idx entry = load-order index (< kCap) | local row << 10
 
 // One pass of a wave over the stream positions lo + first + k * stride < hi (sorted by row); books
@@ -414,7 +418,6 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
     YR_STAMP(1);
     RowSums<LPR, GPW> sums;
     sums.clear();
-    float4 acc_heavy = zero4();                  // what the cooperative passes add to this group's own row
 
     for (int tg0 = 0; tg0 < a.T; tg0 += kTileGroup) {
       const int nt = min(kTileGroup, a.T - tg0);
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
 #pragma unroll
               for (int w = 0; w < kWavesPerBlock; ++w) {
                 const float4 h = s_heavy[w][l];
-                acc_heavy.x += h.x; acc_heavy.y += h.y; acc_heavy.z += h.z; acc_heavy.w += h.w;
+                sums.total.x += h.x; sums.total.y += h.y; sums.total.z += h.z; sums.total.w += h.w;
               }
             }
             __syncthreads();
@@ -548,8 +551,7 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
     }
 
     YR_STAMP(3);
-    float4 acc = sums.finish(grp);
-    acc.x += acc_heavy.x; acc.y += acc_heavy.y; acc.z += acc_heavy.z; acc.w += acc_heavy.w;
+    const float4 acc = sums.finish(grp);
     if (valid_f) {
       if (FUSE_ADAM) {
         float4 own = USER ? s_own[row_l * LPR + l] : ld4o(a.own_old, o_f);
@@ -741,8 +743,7 @@ static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU
     ua.nb = p.nbU; ua.T = p.T; ua.tile_stride = p.tile; ua.rows = (int)nU;
     ua.bucket_begin = 0; ua.bucket_end = p.nbU;
     ua.heavy_t = kHeavyRow; ua.inv_batch = inv_batch; ua.adam = adam;
-    int gu = p.nbU < YR_LOSS_PARTIALS ? p.nbU : YR_LOSS_PARTIALS;   // one loss-partial slot per workgroup
-    if (const char* e = getenv("YR_OWNER_GRID")) { const int c = atoi(e); if (c > 0 && gu > c) gu = c; }
+    const int gu = p.nbU < YR_LOSS_PARTIALS ? p.nbU : YR_LOSS_PARTIALS;   // one loss-partial slot per workgroup
     hipLaunchKernelGGL((owner_pass_kernel<D, true, true>), dim3(gu), dim3(kBlock), 0, s, ua);
   }
   const bool items = (phases & YR_PULL_ITEM_PHASE) && item_end > item_begin;
@@ -758,7 +759,6 @@ static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU
     ia.heavy_t = kHeavyRow; ia.inv_batch = inv_batch; ia.adam = adam;
     int gi = ia.bucket_end - ia.bucket_begin;
     if (gi > kMaxOwnerGrid) gi = kMaxOwnerGrid;
-    if (const char* e = getenv("YR_OWNER_GRID")) { const int c = atoi(e); if (c > 0 && gi > c) gi = c; }
     if (gradI_out)
       hipLaunchKernelGGL((owner_pass_kernel<D, false, false>), dim3(gi), dim3(kBlock), 0, s, ia);
     else
