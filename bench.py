@@ -10,11 +10,14 @@ gather + BPR scoring + loss + gradient of both embedding tables + dense Adam on 
 (reference trainers/mf_trainer.py:104-112), inputs already resident in HBM.  At N > 1 the
 interaction matrix is sharded by user (one rank per GPU, its users' rows + Adam state local,
 the item table replicated) with one RCCL all-reduce on the item-embedding gradient per step;
-per-GPU batch is fixed ("weak" scaling) and `value` is the whole-job triplets/s.
+per-GPU batch is fixed ("weak" scaling, default; `--scaling strong` fixes the global batch) and
+`value` is the whole-job triplets/s.  The batch never exceeds one epoch of train rows.
 
 Rank 0 prints ONE JSON line (contract in the task statement) that also carries
-  "roofline":     the dominant kernel's achieved algorithmic bytes/s vs the 8 TB/s HBM peak,
-                  its launch durations measured with HIP events inside the timed region;
+  "roofline":     the dominant kernel's achieved algorithmic bytes/s vs the 8 TB/s HBM peak, every
+                  launch between its own pair of HIP events inside the timed region; "step" = all
+                  launches of a batch against SURVEY 8d's 1,560 B per triplet (without and with the
+                  dense-Adam bytes); "batch_sweep" = the same at 32 / 4,096 / 65,536 / 262,144 / one epoch;
   "cpu_baseline": the reference's CPU op sequence (oracle/mf_torch_cpu.py) timed on this
                   host on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -31,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 DIM = 64
-DEFAULT_BATCH = 1 << 20        # triplets per GPU per step (~ one epoch of Yelp2018 train rows)
+DEFAULT_BATCH = 1 << 19        # triplets per GPU per step: two steps per epoch of the ~0.92 M train rows
 
 
 def algorithmic_bytes_per_triplet(dim):
@@ -47,7 +50,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=DEFAULT_BATCH, help="triplets per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU-baseline work")
-    ap.add_argument("--sweep", action="store_true", help="also time other batch sizes (N=1 only)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep (N=1 only; < 1 s of GPU time)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = --batch triplets per GPU; strong = --batch triplets in all (each rank keeps "
+                         "the triplets of the users it owns)")
     ap.add_argument("--workload", default="bpr", choices=["bpr", "eval", "ngcf", "cdae"],
                     help="bpr (default, the BASELINE metric) or one of the other full-size paths (N=1 only): "
                          "eval = fused scoring + mask + top-10 + metrics, ngcf = configs[3] step, cdae = configs[4] step")
@@ -151,6 +157,28 @@ def other_workload(args):
     print(json.dumps(out), flush=True)
 
 
+EVENT_EVERY = 5                # launches are bracketed by HIP events on every 5th timed step: an event pair
+                               # per launch on every step would itself cost ~20 % of a 100 us step
+
+
+def time_steps_gpu(step, batch, steps, warmup):
+    """(seconds per step, kernel-time dict) of `steps` steps on one resident batch; the kernel
+    times come from a few further steps with an event pair around every launch."""
+    u, p, n = batch
+    for _ in range(warmup):
+        step.step(u, p, n)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step.step(u, p, n)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / steps
+    step.reset_timers()
+    for _ in range(10):
+        step.step(u, p, n, record=True)
+    return sec, step.kernel_times()
+
+
 def main():
     args = parse()
     if args.workload != "bpr":
@@ -195,17 +223,30 @@ def main():
     num_users, num_items, nnz = YELP2018_USERS, YELP2018_ITEMS, iu.numel()
     label = split_train_rows(iu, ii, generator=gen)
     tr = label == 0
-    shard = UserShard(num_users, world, rank)
-    mine = tr & (iu >= shard.lo) & (iu < shard.hi)
-    sampler = TripletSampler(iu[mine] - shard.lo, ii[mine], shard.size, num_items, seed=99 + rank)
-    n_train_local = len(sampler)
     n_train_global = int(tr.sum())
-    B = args.batch
+    shard = UserShard(num_users, world, rank)
+    strong = args.scaling == "strong"
+    # the batch never exceeds one epoch of train rows (nothing a DataLoader over the train set could not produce)
+    B = min(args.batch, n_train_global)
     n_pool = max(1, min(4, args.steps + args.warmup))
-    su, sp, sn = sampler.stream(B * n_pool)
-    pool = [(su[k * B:(k + 1) * B].contiguous(), sp[k * B:(k + 1) * B].contiguous(),
-             sn[k * B:(k + 1) * B].contiguous()) for k in range(n_pool)]
-    del su, sp, sn, iu, ii, label, tr, mine
+    if strong:
+        # fixed GLOBAL batch: every rank draws the same global stream and keeps the triplets of its users
+        gs = TripletSampler(iu[tr], ii[tr], num_users, num_items, seed=99)
+        su, sp, sn = gs.stream(B * n_pool)
+        pool = []
+        for k in range(n_pool):
+            gu, gp, gn = (t[k * B:(k + 1) * B] for t in (su, sp, sn))
+            m = (gu >= shard.lo) & (gu < shard.hi)
+            pool.append(((gu[m] - shard.lo).contiguous(), gp[m].contiguous(), gn[m].contiguous()))
+        global_batch = B
+    else:
+        mine = tr & (iu >= shard.lo) & (iu < shard.hi)
+        sampler = TripletSampler(iu[mine] - shard.lo, ii[mine], shard.size, num_items, seed=99 + rank)
+        su, sp, sn = sampler.stream(B * n_pool)
+        pool = [(su[k * B:(k + 1) * B].contiguous(), sp[k * B:(k + 1) * B].contiguous(),
+                 sn[k * B:(k + 1) * B].contiguous()) for k in range(n_pool)]
+        global_batch = B * world
+    del su, sp, sn, iu, ii, label, tr
     data_s = time.time() - t0
 
     # ---- tables: xavier-uniform like models/mf.py:15-18; user rows sharded, items replicated ---
@@ -228,7 +269,7 @@ def main():
             u, p, n = pool[k % n_pool]
             # the following batch is known: at N > 1 its index is built under this step's all-reduce
             nxt = pool[(k + 1) % n_pool] if (world > 1 and k + 1 < steps) else None
-            step.step(u, p, n, record=timed, next_batch=nxt)
+            step.step(u, p, n, record=timed and k % EVENT_EVERY == 0, global_batch=global_batch, next_batch=nxt)
 
     run(args.warmup, False)
     barrier()
@@ -242,72 +283,88 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     step.check()
-    value = world * B * args.steps / elapsed
+    value = global_batch * args.steps / elapsed
+    per_triplet = algorithmic_bytes_per_triplet(DIM)
+    adam_bytes = 6 * 4 * (num_users + num_items) * DIM          # read p,m,v + write p,m,v on every row (fused)
 
-    # ---- roofline of the dominant kernel (HIP events inside the timed region) --------------------
+    # ---- roofline (HIP events inside the timed region, one pair per launch) ----------------------
     kt = step.kernel_times()                     # {name: (avg_us, launches, algorithmic bytes per launch)}
     dom = max(kt, key=lambda k: kt[k][0] * kt[k][1])
     avg_us, launches, alg_bytes = kt[dom]
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
+    group_us = sum(v[0] for v in kt.values())
+    local_B = sum(t[0].numel() for t in pool) / len(pool)
     # HBM-side traffic per step from rocprofv3 PMC passes of this same command (FETCH_SIZE doubled
     # as MI355X_MICROARCH.md prescribes, + WRITE_SIZE), committed under profiles/ by
     # scripts/pmc_traffic.py; null when no such measurement is in the tree.
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if world == 1 and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if tj.get("batch_per_gpu") == B and tj.get("step_impl") == step.impl:
-                traffic = tj["hbm_bytes_per_step"]
+                traffic = tj.get("hbm_bytes_dominant_kernel", tj["hbm_bytes_per_step"])
+                traffic_source = tj.get("source", "profiles/traffic.json (rocprofv3 --pmc passes of this command, earlier run)")
         except (ValueError, KeyError):
             traffic = None
-    roofline = {"bound": "hbm", "kernel": dom + " (launch group: " + step.launches + ")",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": traffic_source,
                 "avg_kernel_us": round(avg_us, 2), "launches": launches,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "kernels_us": {k: round(v[0], 2) for k, v in kt.items()}}
+                "kernels": {k: {"avg_us": round(v[0], 2), "algorithmic_bytes": v[2],
+                                "GBps": round(v[2] / (v[0] * 1e-6) / 1e9, 1)} for k, v in kt.items()},
+                # the whole step (all launches of one batch) against SURVEY 8d's 1,560 B per triplet
+                "step": {"launches": step.launches, "sum_kernel_us": round(group_us, 2),
+                         "algorithmic_bytes": int(local_B * per_triplet),
+                         "frac": round(local_B * per_triplet / (group_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                         "frac_with_adam_bytes": round((local_B * per_triplet + adam_bytes) / (group_us * 1e-6) / 1e9
+                                                       / HBM_PEAK_GBS, 4),
+                         "frac_wall": round(local_B * per_triplet / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}}
 
     out = {
         "metric": "BPR triplets/sec @ dim64", "value": round(value, 1), "unit": "triplets/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BPR-MF dim=64 train step (gather+score+loss+grad+dense Adam), "
                                "synthetic Yelp2018 shape, user-sharded" if world > 1 else
                                "BPR-MF dim=64 train step (gather+score+loss+grad+dense Adam), synthetic Yelp2018 shape",
                    "users": num_users, "items": num_items, "interactions": nnz,
-                   "train_triplets_per_epoch": n_train_global, "batch_per_gpu": B, "global_batch": B * world,
+                   "train_triplets_per_epoch": n_train_global, "batch_per_gpu": int(local_B) if strong else B,
+                   "global_batch": global_batch,
                    "optimizer": "adam(dense)", "parallelism": f"user-shard x{world}" if world > 1 else "single",
                    "step_impl": step.impl, "data_gen_s": round(data_s, 1)},
         "roofline": roofline,
     }
 
-    if rank == 0 and world == 1 and args.sweep:
+    if rank == 0 and world == 1 and not args.no_sweep:
+        # the step at the batch sizes training runs use (reference default 32 ... one epoch per step)
         sweep = {}
-        for b in (32, 4096, 65536, 262144):
-            uu, pp, nn = (t[:b].contiguous() for t in pool[0])
-            for _ in range(5):
-                step.step(uu, pp, nn)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(50):
-                step.step(uu, pp, nn)
-            torch.cuda.synchronize()
-            sweep[str(b)] = round(b * 50 / (time.perf_counter() - t1), 1)
-        out["batch_sweep_triplets_per_s"] = sweep
+        for b in (32, 4096, 65536, 262144, n_train_global):
+            if b > pool[0][0].numel() * n_pool:
+                continue
+            src = torch.cat([t[0] for t in pool])[:b], torch.cat([t[1] for t in pool])[:b], torch.cat([t[2] for t in pool])[:b]
+            sec, k2 = time_steps_gpu(step, tuple(t.contiguous() for t in src), 50, 10)
+            ksum = sum(v[0] for v in k2.values()) * 1e-6
+            sweep[str(b)] = {"us_per_step": round(sec * 1e6, 1), "triplets_per_s": round(b / sec, 1),
+                             "impl": step.impl.split(":")[0], "sum_kernel_us": round(ksum * 1e6, 1),
+                             "frac": round(b * per_triplet / sec / 1e9 / HBM_PEAK_GBS, 4),
+                             "frac_with_adam_bytes": round((b * per_triplet + adam_bytes) / sec / 1e9 / HBM_PEAK_GBS, 4)}
+        out["batch_sweep"] = sweep
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.mf_torch_cpu import time_steps      # CPU baseline leg only (never the product path)
-        cpu_b = min(B, 1 << 20)
+        cpu_b = B
         cpu_batches = [tuple(t[:cpu_b].cpu() for t in pool[k]) for k in range(min(2, n_pool))]
         tps, csteps, csec = time_steps(num_users, num_items, DIM, cpu_batches, budget_s=args.cpu_budget)
         out["cpu_baseline"] = {"value": round(tps, 1), "unit": "triplets/s", "cores": torch.get_num_threads(),
                                "kind": "port",
                                "sample": f"{csteps} steps of batch {cpu_b} (same tables/shape/stream), {csec:.1f} s, "
                                          "torch-CPU op sequence of mf_trainer.py:104-114 with dense Adam"}
-        if args.sweep:
-            # SURVEY.md §8d: the CPU op sequence at the reference's default batch and two larger ones
+        if not args.no_sweep:
+            # SURVEY.md 8d: the CPU op sequence at the reference's default batch and two larger ones
             cs = {}
             for b in (32, 4096, 65536):
                 cb = [tuple(t[:b].cpu() for t in pool[k]) for k in range(min(2, n_pool))]

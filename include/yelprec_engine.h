@@ -177,8 +177,10 @@ int yr_bpr_mf_pull_step(const float *U_old, float *U_new, float *I,
  *                         rows [item_row_begin, item_row_end) only, so the item gradient can be
  *                         produced (and all-reduced) in chunks; both bounds must be multiples of
  *                         the bucket size 1024/D (item_row_end may also equal num_items).  The user
- *                         phase must have run for the batch before any item phase; the loss is
- *                         finalized by the call that runs the user phase.
+ *                         phase must have run for the batch before any item phase.  The call that
+ *                         is given loss_out / loss_accum reduces the loss partials of the user
+ *                         phase (in its item launch, or a one-workgroup launch if it has none):
+ *                         pass them to exactly one call per batch, not before the user phase.
  * yr_bpr_mf_pull_step == index, then apply with both phases over all item rows.             */
 int yr_bpr_mf_pull_index(const int64_t *user, const int64_t *pos, const int64_t *neg, int64_t B, int D,
                          int64_t num_users, int64_t num_items,

@@ -197,9 +197,10 @@ class BPRMFStep:
         both = engine.PULL_USER_PHASE | engine.PULL_ITEM_PHASE
         ploss, paccum = self.loss.data_ptr(), self.loss_accum.data_ptr()
 
-        def apply(phases, r0, r1):
+        def apply(phases, r0, r1, with_loss=None):
             ws = self._ws_slots[slot]
-            with_loss = bool(phases & engine.PULL_USER_PHASE)   # that call's last launch reduces the loss
+            if with_loss is None:
+                with_loss = bool(phases & engine.PULL_USER_PHASE)   # that call's last launch reduces the loss
             step_size, bc2_sqrt = engine.adam_scalars(self.t, self.lr, self.betas[0], self.betas[1])
             rc = self._lib.yr_bpr_mf_pull_apply(
                 self.U.data_ptr(), self._U_alt.data_ptr(), self._pI, self._pmU, self._pvU, self._pmI, self._pvI,
@@ -221,6 +222,18 @@ class BPRMFStep:
                 self._indexed = None
 
         def local_first():
+            if record and self.time_kernels and not multi:
+                # the same three launches, each between its own pair of events; algorithmic bytes per
+                # SURVEY 8d split by what each launch must move at least once (ids, partner rows,
+                # gradient rows folded into the Adam pass; the dense Adam bytes listed apart)
+                self._timed("tile_partition", B * 24, record,
+                            lambda: None if ready else self._build_index(u, p, n, slot))
+                self._timed("owner_pass_user", B * (16 * D), record,   # 3 rows read + the user gradient row
+                            lambda: apply(engine.PULL_USER_PHASE, 0, 0, with_loss=False))
+                self._timed("owner_pass_item", B * (8 * D), record,    # the two item gradient rows
+                            lambda: apply(engine.PULL_ITEM_PHASE, bounds[0], bounds[1], with_loss=True))
+                self._indexed = None
+                return
             self._timed("bpr_pull_step", alg, record, first_chunk)
 
         def make_chunk(c):

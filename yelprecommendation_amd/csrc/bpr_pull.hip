@@ -734,7 +734,7 @@ static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU
   using G = PullGeom<D>;
   const PullPlan p = make_plan(B, nU, nI, D, false);
   char* w = static_cast<char*>(workspace);
-  const bool want_loss = (loss_out || loss_accum) && (phases & YR_PULL_USER_PHASE);
+  const bool want_loss = loss_out || loss_accum;
   if (phases & YR_PULL_USER_PHASE) {
     OwnerArgs ua{};
     ua.own_old = U_old; ua.own_new = U_new; ua.other = I; ua.m = mU; ua.v = vU; ua.grad_out = nullptr;
