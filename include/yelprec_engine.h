@@ -403,6 +403,26 @@ int yr_csr_rows_to_dense(const int64_t *ptr, const int64_t *idx, const int64_t *
 int yr_negative_mask(const float *positives, int64_t B, int64_t num_items, int neg_times, uint64_t seed,
                      float *out, int32_t *err_flag, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Device-side BPR triplet stream   (reference train.py:76-77: DataLoader(MFDataset, shuffle=True);
+ *   data/datasets/mf_dataset.py:18-32: __getitem__ + _negative_sampling)
+ * Stream positions [first, first + count) of epoch `epoch`: position t reads row P(t) of
+ * (row_user, row_item) — P a keyed pseudo-random permutation of [0, n_rows) when `shuffle`, the
+ * identity otherwise — and draws neg uniformly from [0, num_items), redrawing while it is in the
+ * user's avoid list (CSR avoid_ptr[num_users + 1] / avoid_idx, ascending and duplicate-free inside a
+ * user; the reference avoids the train positives for train rows, train + valid positives for valid
+ * rows: mf_data_pipeline.py:47-48).  A pure function of (seed, epoch, t): stateless, no host
+ * synchronisation, any slice of an epoch on its own.  The generator is the engine's (Feistel + Philox),
+ * not NumPy's: parity runs replay recorded streams.  user_out / pos_out / neg_out: int64[count].
+ * num_items < 2^32.  A user whose avoid list covers the whole catalogue sets YR_FLAG_BAD_ITEM.
+ * ------------------------------------------------------------------------- */
+int yr_triplet_sample(const int64_t *row_user, const int64_t *row_item, int64_t n_rows,
+                      const int64_t *avoid_ptr, const int64_t *avoid_idx,
+                      int64_t num_users, int64_t num_items, uint64_t seed, uint64_t epoch, int shuffle,
+                      int64_t first, int64_t count,
+                      int64_t *user_out, int64_t *pos_out, int64_t *neg_out,
+                      int32_t *err_flag, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

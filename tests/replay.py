@@ -3,23 +3,7 @@ import numpy as np
 import torch
 
 
-class ReplayLoader:
-    """Yields the recorded batches of ONE epoch, as the reference's DataLoader would
-    (dict of int64 tensors), so trainers can be driven by a golden triplet stream."""
-
-    def __init__(self, u, p, n, batch_sizes):
-        self.u, self.p, self.n = (torch.from_numpy(np.ascontiguousarray(a).astype(np.int64)) for a in (u, p, n))
-        self.sizes = [int(b) for b in batch_sizes]
-
-    def __iter__(self):
-        pos = 0
-        for b in self.sizes:
-            s = slice(pos, pos + b)
-            yield {"user_id": self.u[s], "pos_item": self.p[s], "neg_item": self.n[s]}
-            pos += b
-
-    def __len__(self):
-        return len(self.sizes)
+from yelprecommendation_amd.data.triplets import RecordedStream as ReplayLoader  # noqa: E402,F401  (the product's replay mode)
 
 
 def epoch_slices(steps, batch_sizes):

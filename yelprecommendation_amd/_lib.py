@@ -68,6 +68,8 @@ SIGNATURES = {
     "yr_csr_rows_to_dense": [_p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p],
     "yr_negative_mask": [_p, _i64, _i64, _int, C.c_uint64, _p, _p, _p],
     "yr_sgd_dense": [_p, _p, _i64, _d, _d, _int, _p],
+    "yr_triplet_sample": [_p, _p, _i64, _p, _p, _i64, _i64, C.c_uint64, C.c_uint64, _int, _i64, _i64,
+                          _p, _p, _p, _p, _p],
 }
 
 _lib = None

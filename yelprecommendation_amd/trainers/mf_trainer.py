@@ -19,7 +19,7 @@ Differences underneath (results equal to float rounding):
 Multi-GPU (new; the reference is single-process): when ``torch.distributed`` is initialised with
 more than one rank, the interaction matrix is sharded by user.  Every rank runs the
 same script on the same seeded loaders; of each global batch it trains the triplets of the users
-it owns (``UserShard.select``), the item gradient is all-reduced inside ``BPRMFStep`` (RCCL), the
+it owns (the epoch is cut by owner once, on the device), the item gradient is all-reduced inside ``BPRMFStep`` (RCCL), the
 user rows are exchanged once per epoch, ``evaluate`` scores only the rank's users and sums the
 per-user metric terms with one 6-double all-reduce, and only rank 0 writes ``best_model.pt``.
 """
@@ -65,6 +65,7 @@ class MFTrainer(BaseTrainer):
         self.world_size = dist.get_world_size() if dist else 1
         self.rank = dist.get_rank() if dist else 0
         self.shard = UserShard(num_users, self.world_size, self.rank)
+        self._step = None                                  # the BPRMFStep, kept across epochs
 
     def _loss(self):
         return BPRLoss()
@@ -114,12 +115,24 @@ class MFTrainer(BaseTrainer):
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         sU, sI = self.optimizer.state[U], self.optimizer.state[I]
         lo, hi = self.shard.lo, self.shard.hi              # the whole table on one GPU
-        return BPRMFStep(U.data[lo:hi], I.data, lr=group["lr"], betas=group["betas"], eps=group["eps"],
-                         weight_decay=group["weight_decay"],
-                         optimizer="adamw" if self.optimizer._decoupled else "adam",
-                         world_size=self.world_size,
-                         state=dict(mU=sU["exp_avg"][lo:hi], vU=sU["exp_avg_sq"][lo:hi], mI=sI["exp_avg"],
-                                    vI=sI["exp_avg_sq"], t=sU["step"]))
+        # one step object for the whole run (its second user buffer, workspaces and partials are
+        # allocated once); rebuilt only when the tensors it is bound to were replaced, e.g. by
+        # optimizer.load_state_dict()
+        bound = (U.data[lo:hi].data_ptr(), I.data.data_ptr(), sU["exp_avg"].data_ptr(), sU["exp_avg_sq"].data_ptr(),
+                 sI["exp_avg"].data_ptr(), sI["exp_avg_sq"].data_ptr(), group["lr"], group["betas"], group["eps"],
+                 group["weight_decay"])
+        st = self._step
+        if st is not None and self._step_bound[1:] == bound[1:] and st.U.data_ptr() == bound[0]:
+            st.t = int(sU["step"])
+            return st
+        self._step = BPRMFStep(U.data[lo:hi], I.data, lr=group["lr"], betas=group["betas"], eps=group["eps"],
+                               weight_decay=group["weight_decay"],
+                               optimizer="adamw" if self.optimizer._decoupled else "adam",
+                               world_size=self.world_size,
+                               state=dict(mU=sU["exp_avg"][lo:hi], vU=sU["exp_avg_sq"][lo:hi], mI=sI["exp_avg"],
+                                          vI=sI["exp_avg_sq"], t=sU["step"]))
+        self._step_bound = bound
+        return self._step
 
     def _exchange_user_rows(self):
         """Every rank receives the rows the other ranks trained (once per epoch, 8 MB in total)."""
@@ -146,13 +159,26 @@ class MFTrainer(BaseTrainer):
             return float(self._loss_accum.item())
         U, I = self.model.user_embedding.weight, self.model.item_embedding.weight
         if self.world_size > 1:
-            for data in train_dataloader:
-                user_id, pos_item, neg_item = self._batch(data)
-                mine = [t.contiguous() for t in self.shard.select(user_id, pos_item, neg_item)]
-                step.step(*mine, global_batch=user_id.numel())
+            # The loaders do not depend on the model, so the epoch's batches are drawn first and cut by
+            # owner ONCE on the device: one host read-back per epoch (the per-batch counts) instead of a
+            # boolean-mask selection — and its synchronisation — in front of every step.
+            batches = [self._batch(data) for data in train_dataloader]
+            sizes = [b[0].numel() for b in batches]
+            if batches:
+                eu, ep, en = (torch.cat([b[k] for b in batches]) for k in range(3))
+                mine = self.shard.mine(eu)
+                batch_of = torch.repeat_interleave(torch.arange(len(sizes), device=eu.device),
+                                                   torch.tensor(sizes, device=eu.device))
+                counts = torch.bincount(batch_of[mine], minlength=len(sizes)).tolist()
+                lu, lp, ln = self.shard.localize(eu[mine]).contiguous(), ep[mine].contiguous(), en[mine].contiguous()
+                at = 0
+                for size, c in zip(sizes, counts):
+                    step.step(lu[at:at + c], lp[at:at + c], ln[at:at + c], global_batch=size)
+                    at += c
             own = U.data[self.shard.lo:self.shard.hi]
             if step.U.data_ptr() != own.data_ptr():
                 own.copy_(step.U)
+                step.U, step._U_alt = own, step.U          # keep the step bound to the module's rows
             self._exchange_user_rows()
         else:
             for data in train_dataloader:
@@ -161,8 +187,30 @@ class MFTrainer(BaseTrainer):
             U.data = step.U
         self.optimizer.state[U]["step"] = self.optimizer.state[I]["step"] = step.t
         total = step.epoch_loss()
+        if self.world_size > 1:
+            # every rank learns of a bad index on any rank and raises with it (a rank raising alone
+            # would leave its peers blocked in the next collective)
+            _dist().all_reduce(step.flag, op=_dist().ReduceOp.MAX)
         step.check()
         return total
+
+    def save_checkpoint(self, path, **extra):
+        """As BaseTrainer.save_checkpoint; when the run is user-sharded, rank r holds the current Adam
+        moments of ITS user rows only, so the slices are exchanged first and rank 0 writes the file."""
+        if self.world_size > 1:
+            U = self.model.user_embedding.weight
+            st = self.optimizer.state.get(U, {})
+            for name in ("exp_avg", "exp_avg_sq"):
+                if name in st:
+                    for r in range(self.world_size):
+                        lo, hi = self.shard.bounds(r)
+                        if hi > lo:
+                            _dist().broadcast(st[name][lo:hi], src=r)
+            if self.rank == 0:
+                super().save_checkpoint(path, **extra)
+            _dist().barrier()
+            return
+        super().save_checkpoint(path, **extra)
 
     def validate(self, valid_dataloader) -> float:
         # reference mf_trainer.py:118-132
