@@ -123,3 +123,26 @@ def test_full_size_epoch_properties(device):
     s.check()
     su, sp, sn = s.stream(2 * len(s) + 5)
     assert su.numel() == 2 * len(s) + 5
+
+
+def test_sampler_from_dataset_avoids_train_and_valid_positives(device, golden_dir):
+    """MFDataset.to_sampler on the VALID rows of the golden frame: negatives avoid the rows' pos_items lists
+    = train + valid positives (reference mf_data_pipeline.py:47-48)."""
+    import os
+    import pandas as pd
+    from yelprecommendation_amd.data.datasets.mf_data_pipeline import MFDataPipeline
+    from yelprecommendation_amd.data.datasets.mf_dataset import MFDataset
+    from yelprecommendation_amd.utils import make_config
+    g = np.load(os.path.join(golden_dir, "mf_small.npz"))
+    df = pd.DataFrame({"user_id": g["tsv_user"].astype(np.int64), "business_id": g["tsv_item"].astype(np.int64),
+                       "rating": g["tsv_rating"].astype(np.int64)})
+    pipe = MFDataPipeline(make_config("MF", seed=int(g["seed"]) if "seed" in g.files else 42))
+    pipe._set_num_items_and_num_users(df)
+    train, valid, _, _ = pipe.split(df)
+    s = MFDataset(valid, num_items=pipe.num_items).to_sampler(device, pipe.num_users)
+    u, p, n = s.epoch()
+    assert u.numel() == len(valid)
+    keys = set((int(a) * pipe.num_items + int(b)) for a, b in
+               zip(np.r_[train.user_id.values, valid.user_id.values], np.r_[train.business_id.values, valid.business_id.values]))
+    assert not any((int(a) * pipe.num_items + int(b)) in keys for a, b in zip(u.cpu().tolist(), n.cpu().tolist()))
+    assert sorted((u * pipe.num_items + p).cpu().tolist()) == sorted((valid.user_id.values * pipe.num_items + valid.business_id.values).tolist())
