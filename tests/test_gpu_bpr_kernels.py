@@ -6,6 +6,8 @@ import torch
 from oracle import adam as oadam
 from oracle import bpr_mf as obpr
 
+from replay import assert_topk_equal_up_to_near_ties
+
 pytestmark = pytest.mark.gpu
 
 # float32 parity: the kernels reassociate sums (wave shuffles, float atomics), so
@@ -182,7 +184,7 @@ def test_mf_recommend_matches_oracle(device, fused):
                               torch.from_numpy(users).to(device), torch.from_numpy(ptr).to(device),
                               torch.from_numpy(idx).to(device), k, chunk_users=64, fused=fused).cpu().numpy()
     want = mf_eval.recommend(U, I, users, ptr, idx, k)
-    assert (got == want).all(axis=1).mean() >= 0.99
+    assert_topk_equal_up_to_near_ties(got, want, U, I, users, lists)     # every differing row is a near-tie
     for r in range(nu):
         assert not set(got[r].tolist()) & set(lists[r].tolist())
 
@@ -207,7 +209,7 @@ def test_fused_eval_topk_edge_cases(device, d):
     for k in (1, 10, 16):
         a = engine.mf_recommend(t(U), t(I), t(users), t(ptr), t(idx), k, fused=True).cpu().numpy()
         b = engine.mf_recommend(t(U), t(I), t(users), t(ptr), t(idx), k, fused=False).cpu().numpy()
-        assert (a == b).all(axis=1).mean() >= 0.98, (k, (a == b).all(axis=1).mean())
+        assert_topk_equal_up_to_near_ties(a, b, U, I, users, lists)
 
 
 @pytest.mark.parametrize("ni,expect_slices", [(4100, 2), (16411, 8)])
@@ -241,7 +243,7 @@ def test_fused_eval_catalogue_slices_equal_one_slice(device, ni, expect_slices):
         b = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, sliced=False).cpu().numpy()
         np.testing.assert_array_equal(a, b)
         c = engine.mf_recommend(t(U), t(I), t(users), t(ptr), t(idx), k, fused=False).cpu().numpy()
-        assert (a == c).all(axis=1).mean() >= 0.98
+        assert_topk_equal_up_to_near_ties(a, c, U, I, users, lists)
         for r in range(n):
             assert not set(a[r].tolist()) & set(lists[r].tolist())
 
@@ -283,7 +285,10 @@ def test_full_catalogue_eval_properties(device):
     idx = torch.randint(0, ni, (int(ptr[-1]),), device=device, generator=g)
     fused = engine.mf_recommend(U, I, users, ptr, idx, k, fused=True)
     plain = engine.mf_recommend(U, I, users, ptr, idx, k, fused=False)
-    assert (fused == plain).all(1).float().mean().item() >= 0.999
+    lists = [idx[int(ptr[r]):int(ptr[r + 1])].cpu().numpy() for r in range(n)]
+    ndiff = assert_topk_equal_up_to_near_ties(fused.cpu().numpy(), plain.cpu().numpy(), U.cpu().numpy(), I.cpu().numpy(),
+                                              users.cpu().numpy(), lists)
+    assert ndiff <= n // 100                                                  # and near-ties are rare
     scores = (U[users] @ I.t())
     picked = scores.gather(1, fused)
     assert bool((picked[:, :-1] >= picked[:, 1:]).all())                      # descending

@@ -8,7 +8,7 @@ import pandas as pd
 import pytest
 import torch
 
-from replay import ReplayLoader, epoch_slices
+from replay import ReplayLoader, assert_topk_equal_up_to_near_ties, epoch_slices
 
 pytestmark = pytest.mark.gpu
 
@@ -91,10 +91,11 @@ def test_evaluate_and_top10_match_reference(g, tmp_path, device):
     _, users, mask_ptr, mask_idx = t._eval_arrays(test_eval)
     top = t.recommend(users, mask_ptr, mask_idx).cpu().numpy()
     ref = g["top10_test"]
-    # identical lists except where two scores are equal to float rounding
-    same_rows = (top == ref).all(axis=1).mean()
-    assert same_rows >= 0.995, same_rows
-    assert (np.sort(top, axis=1) == np.sort(ref, axis=1)).all(axis=1).mean() >= 0.998
+    # identical lists, except rows where two exact scores are closer than float32 rounding: every differing
+    # row is examined (no agreement quota), and such rows are rare
+    masks = [g["test_mask_idx"][g["test_mask_ptr"][r]:g["test_mask_ptr"][r + 1]] for r in range(len(ref))]
+    ndiff = assert_topk_equal_up_to_near_ties(top, ref, g["U_best"], g["I_best"], users.cpu().numpy(), masks)
+    assert ndiff <= len(ref) // 100
     # single-user entry point of the reference surface
     pred = t.model(torch.full((int(g["num_items"]),), int(users[3]), dtype=torch.int64, device=device),
                    torch.arange(int(g["num_items"]), device=device))
