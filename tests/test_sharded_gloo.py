@@ -32,16 +32,19 @@ def _problem():
     return nu, ni, d, B, U, I, batches
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode="all_reduce"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from yelprecommendation_amd.user_shard import UserShard, sharded_item_exchange
+    from yelprecommendation_amd.user_shard import (ItemSlices, UserShard, reduce_scatter_item_exchange,
+                                                   sharded_item_exchange)
     nu, ni, d, B, U, I, batches = _problem()
     shard = UserShard(nu, world, rank)
     Ul, Il = U[shard.lo:shard.hi].copy(), I.copy()
     mU, vU, mI, vI = (np.zeros_like(a) for a in (Ul, Ul, Il, Il))
-    grad_item = torch.zeros(ni, d)
+    sl = ItemSlices(ni, world, rank, granule=8)
+    grad_item = torch.zeros(sl.padded if mode == "reduce_scatter" else ni, d)
+    param_pad = torch.zeros(sl.padded, d)
     loss_sum = torch.zeros(1, dtype=torch.float64)
     lr = 5e-3
     for t, (u, p, n) in enumerate(batches, start=1):
@@ -59,12 +62,25 @@ def _worker(rank, world, port, out_dir):
             np.add.at(gI, ln, -g * Ul[lu])
             state["loss"] = float(np.sum(-obpr.log_sigmoid(x), dtype=np.float64)) / B
             oadam.adam_update(Ul, gU, mU, vU, t, lr)             # user rows: local
-            grad_item.copy_(torch.from_numpy(gI))
+            grad_item[:ni].copy_(torch.from_numpy(gI))
 
         def item_update():
             oadam.adam_update(Il, grad_item.numpy().copy(), mI, vI, t, lr)
 
-        sharded_item_exchange(local_step, item_update, grad_item, None, world)
+        def slice_update():                                      # Adam on THIS rank's item rows only
+            at = rank * sl.per
+            rows = slice(sl.lo, sl.hi)
+            g = grad_item[at:at + sl.hi - sl.lo].numpy().copy()
+            p, m, v = Il[rows].copy(), mI[rows].copy(), vI[rows].copy()
+            oadam.adam_update(p, g, m, v, t, lr)
+            Il[rows], mI[rows], vI[rows] = p, m, v
+            param_pad[at:at + sl.hi - sl.lo].copy_(torch.from_numpy(p))
+
+        if mode == "reduce_scatter":
+            reduce_scatter_item_exchange(local_step, slice_update, grad_item, param_pad, sl)
+            Il[:] = param_pad[:ni].numpy()                       # the all-gathered table
+        else:
+            sharded_item_exchange(local_step, item_update, grad_item, None, world)
         loss_sum += state["loss"]
     dist.all_reduce(loss_sum)                                     # BPRMFStep.epoch_loss
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), U=Ul, I=Il, lo=shard.lo, hi=shard.hi,
@@ -73,9 +89,12 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(300)
-def test_user_sharded_step_equals_single_process(tmp_path):
+@pytest.mark.parametrize("mode", ["all_reduce", "reduce_scatter"])
+def test_user_sharded_step_equals_single_process(tmp_path, mode):
+    """Both forms of the exchange: all-reduce + replicated item Adam, and reduce-scatter + item Adam on the
+    rank's slice + all-gather (the item moments of a rank are then current on its slice only)."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
     nu, ni, d, B, U, I, batches = _problem()
     ref = obpr.MFState(U, I, "adam", lr=5e-3)
     total = sum(float(ref.train_step(u, p, n)) for (u, p, n) in batches)

@@ -22,7 +22,7 @@ Two implementations of the same step:
 import torch
 
 from . import engine
-from .user_shard import sharded_item_exchange
+from .user_shard import ItemSlices, reduce_scatter_item_exchange, sharded_item_exchange
 
 
 # impl="auto": the pull form from this many triplets per rank and step upwards, the two-launch atomic
@@ -41,12 +41,21 @@ IMPL_NAMES = {
 class BPRMFStep:
     def __init__(self, U, I, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, optimizer="adam",
                  world_size=1, process_group=None, time_kernels=False, impl="auto", max_batch=0,
-                 state=None, split_item_update=False, item_chunks=2):
+                 state=None, split_item_update=False, item_chunks=2, item_exchange="all_reduce", rank=0):
         """``state``: optional dict with pre-existing Adam tensors ``mU, vU, mI, vI`` (shared, updated
         in place) and the step count ``t`` — lets a trainer keep its torch-style optimizer state
         in sync with the fused step (see MFTrainer).
         ``split_item_update``: take the multi-GPU shape of the step (item pass emits the dense item
         gradient, then a separate dense Adam launch) even with one rank — used by tests."""
+        if item_exchange not in ("all_reduce", "reduce_scatter"):
+            raise ValueError("item_exchange must be 'all_reduce' or 'reduce_scatter'")
+        # N > 1 only.  "all_reduce": the item gradient is summed everywhere and every rank applies the same
+        # dense Adam to its replica (item Adam state replicated).  "reduce_scatter": rank r receives the
+        # summed gradient of ITS slice of the item rows, applies Adam to that slice alone (1/N of the
+        # update, item Adam state sharded: only the slice's moments are current on a rank) and the
+        # updated slices are all-gathered.
+        self.item_exchange = item_exchange
+        self.rank = int(rank)
         self.split_item_update = split_item_update
         # multi-GPU: the item pass / all-reduce / item Adam run in this many chunks of item rows so
         # that chunk c is on the wire while chunk c+1 is computed
@@ -71,6 +80,12 @@ class BPRMFStep:
         # buffers are created on first use by the implementation that needs them
         self.gU = None
         self.gI = torch.zeros_like(I) if (world_size > 1 or split_item_update) else None
+        self._slices = self._I_pad = None
+        if item_exchange == "reduce_scatter" and (world_size > 1 or split_item_update):
+            self._slices = ItemSlices(I.shape[0], world_size, self.rank)
+            self._gI_pad = torch.zeros(self._slices.padded, I.shape[1], dtype=I.dtype, device=I.device)
+            self.gI = self._gI_pad[:I.shape[0]]                # the kernels write the real rows
+            self._I_pad = torch.zeros(self._slices.padded, I.shape[1], dtype=I.dtype, device=I.device)
         if state is not None:
             self.mU, self.vU, self.mI, self.vI = state["mU"], state["vU"], state["mI"], state["vI"]
             self.t = int(state.get("t", 0))
@@ -145,6 +160,8 @@ class BPRMFStep:
             # decided from quantities that are equal on every rank (the two forms issue different
             # collectives): global batch and the table shapes
             key = "pull" if (global_batch >= AUTO_PULL_MIN_BATCH * self.world_size and self._pull_ok) else "atomic"
+            if self._slices is not None:
+                key = "pull"                        # sharded item Adam state: one form for the whole run
         if key == "pull":
             if self._U_alt is None:
                 self._U_alt = torch.empty_like(self.U)
@@ -256,6 +273,28 @@ class BPRMFStep:
                         self.betas[0], self.betas[1], self.eps, self.wd, decoupled=self.decoupled, zero_grad=False))
             return run
 
+        if multi and self._slices is not None:
+            sl = self._slices
+
+            def whole_item_pass():
+                local_first()
+                for c in range(1, nchunks):
+                    make_chunk(c)()
+
+            def slice_update():
+                lo, hi, at = sl.lo, sl.hi, sl.rank * sl.per
+                if hi > lo:
+                    self._timed("adam_dense_item_slice", 7 * 4 * (hi - lo) * D, record, lambda: engine.adam_dense(
+                        self.I[lo:hi], self._gI_pad[at:at + hi - lo], self.mI[lo:hi], self.vI[lo:hi], self.t, self.lr,
+                        self.betas[0], self.betas[1], self.eps, self.wd, decoupled=self.decoupled, zero_grad=False))
+                    self._I_pad[at:at + hi - lo].copy_(self.I[lo:hi])
+
+            reduce_scatter_item_exchange(whole_item_pass, slice_update, self._gI_pad, self._I_pad, sl, self.pg, overlap)
+            if self.world_size > 1:
+                self.I.copy_(self._I_pad[:rows])
+            self._gI_dirty = True
+            self.U, self._U_alt = self._U_alt, self.U
+            return
         steps = [local_first] + [make_chunk(c) for c in range(1, nchunks)]
         grads = [self.gI[bounds[c]:bounds[c + 1]] for c in range(nchunks)] if multi else [None]
         sharded_item_exchange(steps, [make_update(c) for c in range(nchunks)], grads, self.pg, self.world_size,

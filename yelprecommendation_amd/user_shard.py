@@ -48,8 +48,60 @@ class UserShard:
         return (self.localize(user_id[m]),) + tuple(o[m] for o in others)
 
 
+class ItemSlices:
+    """Equal slices of the (replicated) item rows for the reduce-scatter form of the exchange: rank r
+    owns rows [r * per, min(rows, (r + 1) * per)), per = ceil(rows / world) rounded up to ``granule`` rows;
+    buffers that take part in the collectives are padded to world * per rows."""
+
+    def __init__(self, rows: int, world_size: int, rank: int, granule: int = 64):
+        per = -(-int(rows) // int(world_size))
+        self.per = -(-per // granule) * granule
+        self.rows, self.world_size, self.rank = int(rows), int(world_size), int(rank)
+        self.padded = self.per * self.world_size
+        self.lo = min(self.rows, self.rank * self.per)
+        self.hi = min(self.rows, self.lo + self.per)
+
+
 def _as_list(x):
     return list(x) if isinstance(x, (list, tuple)) else [x]
+
+
+def reduce_scatter_item_exchange(local_step, slice_update, grad_padded, param_padded, slices, group=None, overlap=None):
+    """The other form of the exchange (one chunk): every rank keeps the Adam state of ONE slice of the item
+    rows only.
+
+        local_step()                        as in sharded_item_exchange; leaves the dense local item gradient
+                                            in ``grad_padded[:rows]`` (padding rows zero)
+        reduce_scatter(SUM)                 rank r receives the summed gradient of ITS slice (into its
+                                            own slice of ``grad_padded``)
+        overlap()                           optional independent work
+        slice_update()                      Adam on the rank's slice of the item rows (1/world of the
+                                            dense item update and of its state traffic); must leave the
+                                            updated rows in ``param_padded[lo_pad : lo_pad + per]``
+        all_gather                          every rank receives every slice -> ``param_padded``
+
+    Same wire volume as the ring all-reduce (2 (N-1)/N of the table per rank).  RCCL:
+    reduce_scatter_tensor / all_gather_into_tensor; backends without reduce-scatter (gloo in the CPU
+    tests) take all_reduce + the own slice, and all_gather over the slice list."""
+    import torch.distributed as dist
+    local_step()
+    w, per, r = slices.world_size, slices.per, slices.rank
+    mine = grad_padded[r * per:(r + 1) * per]
+    if w > 1:
+        if dist.get_backend(group) == "nccl":
+            dist.reduce_scatter_tensor(mine, grad_padded, op=dist.ReduceOp.SUM, group=group)
+        else:
+            dist.all_reduce(grad_padded, op=dist.ReduceOp.SUM, group=group)
+    if overlap is not None:
+        overlap()
+    slice_update()
+    if w > 1:
+        own = param_padded[r * per:(r + 1) * per]
+        if dist.get_backend(group) == "nccl":
+            dist.all_gather_into_tensor(param_padded, own, group=group)
+        else:
+            parts = [param_padded[k * per:(k + 1) * per] for k in range(w)]
+            dist.all_gather(parts, own.clone(), group=group)
 
 
 def sharded_item_exchange(local_step, item_update, grad_item, group=None, world_size=1, overlap=None):
