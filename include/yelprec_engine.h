@@ -152,6 +152,11 @@ int yr_adam_dense_dual(float *p0, float *g0, float *m0, float *v0, int64_t n0,
  *   loss_out (float[1]) / loss_accum (double[1]), either may be NULL: the step's mean loss
  *          (sum of partials x inv_batch) is stored / added there by the item pass;
  *   lr..weight_decay, step_size, bc2_sqrt, mode: as for yr_adam_dense;
+ *   deterministic: non-zero = bitwise reproducible results (the reference is, under a seed: SURVEY 8c):
+ *          the contributions of a row are summed in triplet order (the owner pass re-ranks every row by
+ *          triplet id after its LDS sort) and chunks are cut at tile boundaries; costs a few percent.
+ *          Exception: a bucket that receives more than one chunk (768 / 1024 records) from a SINGLE
+ *          tile of the batch is cut inside that tile's segment, in arrival order;
  *   workspace: >= yr_bpr_mf_pull_workspace_bytes(B, num_users, num_items, D) bytes, 16-byte
  *          aligned, contents irrelevant on entry (a size computed for max_batch serves every
  *          B <= max_batch).
@@ -163,7 +168,7 @@ int yr_bpr_mf_pull_step(const float *U_old, float *U_new, float *I,
                         int64_t B, int D, int64_t num_users, int64_t num_items, float inv_batch,
                         double lr, double step_size, double bc2_sqrt,
                         double beta1, double beta2, double eps, double weight_decay, int mode,
-                        void *workspace, int64_t workspace_bytes,
+                        int deterministic, void *workspace, int64_t workspace_bytes,
                         float *loss_partials, float *loss_out, double *loss_accum,
                         int32_t *err_flag, void *stream);
 
@@ -190,7 +195,7 @@ int yr_bpr_mf_pull_apply(const float *U_old, float *U_new, float *I,
                          int64_t B, int D, int64_t num_users, int64_t num_items, float inv_batch,
                          double lr, double step_size, double bc2_sqrt,
                          double beta1, double beta2, double eps, double weight_decay, int mode,
-                         void *workspace, int64_t workspace_bytes,
+                         int deterministic, void *workspace, int64_t workspace_bytes,
                          float *loss_partials, float *loss_out, double *loss_accum,
                          int phases, int64_t item_row_begin, int64_t item_row_end,
                          void *stream);

@@ -58,6 +58,36 @@ def test_pull_step_matches_oracle(device, d, B, skew):
     np.testing.assert_allclose(step.vI.cpu().numpy(), ref.opt.v[1], rtol=1e-3, atol=1e-11)
 
 
+@pytest.mark.parametrize("shape", ["small", "yelp"])
+def test_deterministic_mode_is_bitwise_reproducible(device, shape):
+    """The reference is bit-reproducible under a seed.  deterministic=True: two runs of 50 steps
+    on the same batches give bit-identical tables, Adam moments and loss (rows summed in triplet order,
+    chunks cut at tile boundaries) — and still equal the default mode to rounding."""
+    from yelprecommendation_amd.bpr_step import BPRMFStep
+    g = torch.Generator(device=device).manual_seed(3)
+    nu, ni, d, B, steps = (211, 307, 32, 5000, 50) if shape == "small" else (31668, 38048, 64, 1 << 17, 50)
+    U = (torch.rand(nu, d, generator=g, device=device) - 0.5) * 0.2
+    I = (torch.rand(ni, d, generator=g, device=device) - 0.5) * 0.2
+    batches = []
+    for _ in range(5):
+        u = torch.randint(0, nu, (B,), generator=g, device=device)
+        p = (torch.rand(B, generator=g, device=device).pow(2) * ni).long().clamp_(max=ni - 1)   # some long rows
+        batches.append((u, p, torch.randint(0, ni, (B,), generator=g, device=device)))
+    runs = []
+    for det in (True, True, False):
+        st = BPRMFStep(U.clone(), I.clone(), lr=1e-3, deterministic=det, impl="pull")
+        for k in range(steps):
+            st.step(*batches[k % 5])
+        st.check()
+        runs.append((st.U.clone(), st.I.clone(), st.mU.clone(), st.vU.clone(), st.mI.clone(), st.vI.clone(),
+                     torch.tensor(st.epoch_loss(), dtype=torch.float64)))
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b)
+    torch.testing.assert_close(runs[0][0], runs[2][0], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(runs[0][1], runs[2][1], rtol=1e-3, atol=1e-5)
+    assert abs(runs[0][6].item() - runs[2][6].item()) <= 1e-5 * abs(runs[2][6].item())
+
+
 def test_pull_step_empty_batch_still_decays_state(device):
     """Dense-Adam semantics: a step with no triplets still moves every row (m/v decay)."""
     from yelprecommendation_amd.bpr_step import BPRMFStep

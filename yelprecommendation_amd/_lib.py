@@ -34,7 +34,7 @@ SIGNATURES = {
                            _d, _d, _d, _d, _d, _d, _d, _int, _p, _f, _p, _p, _p],
     "yr_bpr_mf_pull_workspace_bytes": [_i64, _i64, _i64, _int],
     "yr_bpr_mf_pull_step": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _f,
-                            _d, _d, _d, _d, _d, _d, _d, _int, _p, _i64, _p, _p, _p, _p, _p],
+                            _d, _d, _d, _d, _d, _d, _d, _int, _int, _p, _i64, _p, _p, _p, _p, _p],
     "yr_spmm_csr": [_p, _p, _p, _p, _p, _i64, _int, _int, _p, _i64, _int, _p],
     "yr_ngcf_score_fwd": [_p, _int, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _p, _p],
     "yr_ngcf_score_bwd": [_p, _p, _int, _p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p],
@@ -53,7 +53,7 @@ SIGNATURES = {
     "yr_nsbce_bwd": [_p, _p, _p, _p, _p, _i64, _p, _p],
     "yr_bpr_mf_pull_index": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _p, _p],
     "yr_bpr_mf_pull_apply": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _f,
-                             _d, _d, _d, _d, _d, _d, _d, _int, _p, _i64, _p, _p, _p, _int, _i64, _i64, _p],
+                             _d, _d, _d, _d, _d, _d, _d, _int, _int, _p, _i64, _p, _p, _p, _int, _i64, _i64, _p],
     "yr_loss_finalize": [_p, _f, _p, _p, _p],
     "yr_mf_scores_gemm": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _p, _p],
     "yr_mf_eval_topk_workspace_bytes": [_i64, _i64, _int],

@@ -41,7 +41,8 @@ IMPL_NAMES = {
 class BPRMFStep:
     def __init__(self, U, I, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, optimizer="adam",
                  world_size=1, process_group=None, time_kernels=False, impl="auto", max_batch=0,
-                 state=None, split_item_update=False, item_chunks=2, item_exchange="all_reduce", rank=0):
+                 state=None, split_item_update=False, item_chunks=2, item_exchange="all_reduce", rank=0,
+                 deterministic=False):
         """``state``: optional dict with pre-existing Adam tensors ``mU, vU, mI, vI`` (shared, updated
         in place) and the step count ``t`` — lets a trainer keep its torch-style optimizer state
         in sync with the fused step (see MFTrainer).
@@ -54,6 +55,9 @@ class BPRMFStep:
         # summed gradient of ITS slice of the item rows, applies Adam to that slice alone (1/N of the
         # update, item Adam state sharded: only the slice's moments are current on a rank) and the
         # updated slices are all-gathered.
+        # deterministic: two runs on the same batches give bit-identical tables (always the pull form: the
+        # atomic form's float atomics add in arrival order)
+        self.deterministic = bool(deterministic)
         self.item_exchange = item_exchange
         self.rank = int(rank)
         self.split_item_update = split_item_update
@@ -160,8 +164,8 @@ class BPRMFStep:
             # decided from quantities that are equal on every rank (the two forms issue different
             # collectives): global batch and the table shapes
             key = "pull" if (global_batch >= AUTO_PULL_MIN_BATCH * self.world_size and self._pull_ok) else "atomic"
-            if self._slices is not None:
-                key = "pull"                        # sharded item Adam state: one form for the whole run
+            if self._slices is not None or self.deterministic:
+                key = "pull"                        # sharded item Adam state / fixed summation order: one form
         if key == "pull":
             if self._U_alt is None:
                 self._U_alt = torch.empty_like(self.U)
@@ -223,7 +227,7 @@ class BPRMFStep:
                 self.U.data_ptr(), self._U_alt.data_ptr(), self._pI, self._pmU, self._pvU, self._pmI, self._pvI,
                 self.gI.data_ptr() if multi else None, B, D, self.U.shape[0], rows, inv, self.lr,
                 step_size, bc2_sqrt, self.betas[0], self.betas[1], self.eps, self.wd,
-                engine.OPT_ADAMW if self.decoupled else engine.OPT_ADAM,
+                engine.OPT_ADAMW if self.decoupled else engine.OPT_ADAM, 1 if self.deterministic else 0,
                 ws.data_ptr(), ws.numel(), self._ppartials, ploss if with_loss else None,
                 paccum if with_loss else None, phases, r0, r1, engine._stream())
             if rc:

@@ -382,7 +382,7 @@ __device__ __forceinline__ void walk_stream(const OwnerArgs& a, const unsigned s
   if (!HEAVY) sums.book(cur_row >= 0, cur_row - row_base, cur, grp);
 }
 
-template <int D, bool USER, bool FUSE_ADAM>
+template <int D, bool USER, bool FUSE_ADAM, bool DET>
 __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(OwnerArgs a) {
   using G = PullGeom<D>;
   constexpr int R = G::R, LPR = G::LPR, GPW = G::GPW;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
   __shared__ int s_light[kWave + 1];             // the same for light rows only (heavy rows: empty range)
   __shared__ int s_x[CAP];                       // user: pos     item: user            (load order)
   __shared__ int s_y[CAP];                       // user: neg     item: signed coefficient (float bits)
-  __shared__ int s_z[USER ? CAP : 1];            // user: triplet id
+  __shared__ int s_z[(USER || DET) ? CAP : 1];   // triplet id (item pass: | sign bit, kept for the deterministic order only)
   __shared__ unsigned short s_idx[CAP];          // row order -> load order | local row << 10
   __shared__ float4 s_own[USER ? R * LPR : 1];   // user pass: the bucket's own rows (they enter the scores)
   __shared__ float4 s_heavy[kWavesPerBlock][LPR];
@@ -446,8 +446,18 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
       const int total = s_pre[nt];
       YR_STAMP(2);
 
-      for (int c0 = 0; c0 < total; c0 += CAP) {
-        const int cend = min(total, c0 + CAP);
+      for (int c0 = 0, cend = 0; c0 < total; c0 = cend) {
+        cend = min(total, c0 + CAP);
+        if (DET && cend < total) {
+          // cut the chunk at a tile boundary: which records share a chunk must not depend on the
+          // (arbitrary) order inside a tile's segment; a single segment larger than a chunk is cut as it is
+          int tlo = 0, thi = nt;
+          while (thi - tlo > 1) {
+            const int mid = (tlo + thi) >> 1;
+            if (s_pre[mid] <= cend) tlo = mid; else thi = mid;
+          }
+          if (s_pre[tlo] > c0) cend = s_pre[tlo];
+        }
         if (tid < kWave) s_cnt[tid] = 0;
         __syncthreads();
         // load this chunk's records (flattened index -> tile by binary search) into LDS in load
@@ -495,6 +505,7 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
               const int local = (int)((uint32_t)oc[q].x >> kOccShift);
               s_x[c] = oc[q].x & kOccMask;
               s_y[c] = __float_as_int(oc[q].y < 0 ? -g[q] : g[q]);
+              if (DET) s_z[c] = oc[q].y;
               key[q] = local | (atomicAdd(&s_cnt[local], 1) << 8);
             }
         }
@@ -517,6 +528,32 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
             s_idx[s_start[key[q] & 255] + (key[q] >> 8)] =
                 (unsigned short)((tid + q * kBlock) | ((key[q] & 255) << kTagShift));
         __syncthreads();
+        if (DET) {
+          // the ranks above came from LDS atomics in arrival order: re-rank every row by triplet id
+          // (unique inside a row), so that the order of every floating-point sum below is fixed
+          int at[PT];
+          unsigned short ent[PT];
+#pragma unroll
+          for (int q = 0; q < PT; ++q) {
+            const int pos = tid + q * kBlock;
+            at[q] = -1;
+            if (pos < cend - c0) {
+              ent[q] = s_idx[pos];
+              const int r = ent[q] >> kTagShift;
+              const uint32_t mine = (uint32_t)s_z[ent[q] & ((1 << kTagShift) - 1)];
+              const int lo = s_start[r], cnt = s_cnt[r];
+              int before = 0;
+              for (int j = lo; j < lo + cnt; ++j)
+                before += (uint32_t)s_z[s_idx[j] & ((1 << kTagShift) - 1)] < mine ? 1 : 0;
+              at[q] = lo + before;
+            }
+          }
+          __syncthreads();
+#pragma unroll
+          for (int q = 0; q < PT; ++q)
+            if (at[q] >= 0) s_idx[at[q]] = ent[q];
+          __syncthreads();
+        }
         // light rows: wave w walks the records of ITS rows [w GPW, (w+1) GPW), one per lane group and step
         {
           float4 cur = zero4();
@@ -729,8 +766,8 @@ static int make_adam(AdamC& c, double lr, double step_size, double bc2_sqrt, dou
 template <int D>
 static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU, float* vU, float* mI, float* vI,
                            float* gradI_out, int64_t B, int64_t nU, int64_t nI, float inv_batch, const AdamC& adam,
-                           void* workspace, float* loss_partials, float* loss_out, double* loss_accum,
-                           int phases, int64_t item_begin, int64_t item_end, hipStream_t s) {
+                           int deterministic, void* workspace, float* loss_partials, float* loss_out,
+                           double* loss_accum, int phases, int64_t item_begin, int64_t item_end, hipStream_t s) {
   using G = PullGeom<D>;
   const PullPlan p = make_plan(B, nU, nI, D, false);
   char* w = static_cast<char*>(workspace);
@@ -744,7 +781,10 @@ static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU
     ua.bucket_begin = 0; ua.bucket_end = p.nbU;
     ua.heavy_t = kHeavyRow; ua.inv_batch = inv_batch; ua.adam = adam;
     const int gu = p.nbU < YR_LOSS_PARTIALS ? p.nbU : YR_LOSS_PARTIALS;   // one loss-partial slot per workgroup
-    hipLaunchKernelGGL((owner_pass_kernel<D, true, true>), dim3(gu), dim3(kBlock), 0, s, ua);
+    if (deterministic)
+      hipLaunchKernelGGL((owner_pass_kernel<D, true, true, true>), dim3(gu), dim3(kBlock), 0, s, ua);
+    else
+      hipLaunchKernelGGL((owner_pass_kernel<D, true, true, false>), dim3(gu), dim3(kBlock), 0, s, ua);
   }
   const bool items = (phases & YR_PULL_ITEM_PHASE) && item_end > item_begin;
   if (items) {
@@ -759,10 +799,14 @@ static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU
     ia.heavy_t = kHeavyRow; ia.inv_batch = inv_batch; ia.adam = adam;
     int gi = ia.bucket_end - ia.bucket_begin;
     if (gi > kMaxOwnerGrid) gi = kMaxOwnerGrid;
-    if (gradI_out)
-      hipLaunchKernelGGL((owner_pass_kernel<D, false, false>), dim3(gi), dim3(kBlock), 0, s, ia);
+    if (gradI_out && deterministic)
+      hipLaunchKernelGGL((owner_pass_kernel<D, false, false, true>), dim3(gi), dim3(kBlock), 0, s, ia);
+    else if (gradI_out)
+      hipLaunchKernelGGL((owner_pass_kernel<D, false, false, false>), dim3(gi), dim3(kBlock), 0, s, ia);
+    else if (deterministic)
+      hipLaunchKernelGGL((owner_pass_kernel<D, false, true, true>), dim3(gi), dim3(kBlock), 0, s, ia);
     else
-      hipLaunchKernelGGL((owner_pass_kernel<D, false, true>), dim3(gi), dim3(kBlock), 0, s, ia);
+      hipLaunchKernelGGL((owner_pass_kernel<D, false, true, false>), dim3(gi), dim3(kBlock), 0, s, ia);
   } else if (want_loss) {
     hipLaunchKernelGGL(pull_loss_finalize_kernel, dim3(1), dim3(kBlock), 0, s, loss_partials, inv_batch, loss_out,
                        loss_accum);
@@ -774,7 +818,7 @@ extern "C" int yr_bpr_mf_pull_apply(const float* U_old, float* U_new, float* I, 
                                     float* vI, float* gradI_out, int64_t B, int D, int64_t num_users,
                                     int64_t num_items, float inv_batch, double lr, double step_size, double bc2_sqrt,
                                     double beta1, double beta2, double eps, double weight_decay, int mode,
-                                    void* workspace, int64_t workspace_bytes,
+                                    int deterministic, void* workspace, int64_t workspace_bytes,
                                     float* loss_partials, float* loss_out, double* loss_accum, int phases,
                                     int64_t item_row_begin, int64_t item_row_end, void* stream) {
   int rc = pull_check_common(B, D, num_users, num_items, workspace, workspace_bytes);
@@ -793,7 +837,7 @@ extern "C" int yr_bpr_mf_pull_apply(const float* U_old, float* U_new, float* I, 
 #define YR_APPLY_CASE(DD)                                                                                       \
   case DD:                                                                                                      \
     return pull_apply_impl<DD>(U_old, U_new, I, mU, vU, mI, vI, gradI_out, B, num_users, num_items, inv_batch,  \
-                               c, workspace, loss_partials, loss_out, loss_accum, phases,      \
+                               c, deterministic ? 1 : 0, workspace, loss_partials, loss_out, loss_accum, phases,      \
                                item_row_begin, item_row_end, s)
   switch (D) {
     YR_APPLY_CASE(16);
@@ -809,7 +853,7 @@ extern "C" int yr_bpr_mf_pull_step(const float* U_old, float* U_new, float* I, f
                                    float* vI, float* gradI_out, const int64_t* user, const int64_t* pos,
                                    const int64_t* neg, int64_t B, int D, int64_t num_users, int64_t num_items,
                                    float inv_batch, double lr, double step_size, double bc2_sqrt, double beta1,
-                                   double beta2, double eps, double weight_decay, int mode,
+                                   double beta2, double eps, double weight_decay, int mode, int deterministic,
                                    void* workspace, int64_t workspace_bytes, float* loss_partials, float* loss_out,
                                    double* loss_accum, int32_t* err_flag, void* stream) {
   if (mode != YR_OPT_ADAM && mode != YR_OPT_ADAMW) return YR_ERR_UNSUPPORTED;
@@ -819,7 +863,7 @@ extern "C" int yr_bpr_mf_pull_step(const float* U_old, float* U_new, float* I, f
                                 stream);
   if (rc) return rc;
   return yr_bpr_mf_pull_apply(U_old, U_new, I, mU, vU, mI, vI, gradI_out, B, D, num_users, num_items, inv_batch, lr,
-                              step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, mode, workspace,
+                              step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, mode, deterministic, workspace,
                               workspace_bytes, loss_partials, loss_out, loss_accum,
                               YR_PULL_USER_PHASE | YR_PULL_ITEM_PHASE, 0, num_items, stream);
 }

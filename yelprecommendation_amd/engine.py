@@ -147,7 +147,7 @@ def bpr_mf_pull_workspace(max_batch, num_users, num_items, d, device):
 
 def bpr_mf_pull_step(U_old, U_new, I, mU, vU, mI, vI, user, pos, neg, step, lr, loss_partials, workspace,
                      beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, decoupled=False, inv_batch=None,
-                     gradI_out=None, err_flag=None, loss_out=None, loss_accum=None):
+                     gradI_out=None, err_flag=None, loss_out=None, loss_accum=None, deterministic=False):
     """One whole BPR-MF step (forward, loss, both gradients, dense Adam) without float atomics.
 
     reference trainers/mf_trainer.py:106-112.  Reads ``U_old``, writes ``U_new`` (distinct
@@ -173,7 +173,7 @@ def bpr_mf_pull_step(U_old, U_new, I, mU, vU, mI, vI, user, pos, neg, step, lr, 
         _opt(gradI_out, f32, "gradI_out"),
         _dev(user, torch.int64, "user"), _dev(pos, torch.int64, "pos"), _dev(neg, torch.int64, "neg"),
         B, d, nu, ni, float(inv_batch), float(lr), float(step_size), float(bc2_sqrt), float(beta1), float(beta2),
-        float(eps), float(weight_decay), OPT_ADAMW if decoupled else OPT_ADAM,
+        float(eps), float(weight_decay), OPT_ADAMW if decoupled else OPT_ADAM, 1 if deterministic else 0,
         _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
         _dev(loss_partials, f32, "loss_partials"), _opt(loss_out, f32, "loss_out"),
         _opt(loss_accum, torch.float64, "loss_accum"), _opt(err_flag, torch.int32, "err_flag"), _stream()),

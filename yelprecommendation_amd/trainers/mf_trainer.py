@@ -128,7 +128,9 @@ class MFTrainer(BaseTrainer):
         self._step = BPRMFStep(U.data[lo:hi], I.data, lr=group["lr"], betas=group["betas"], eps=group["eps"],
                                weight_decay=group["weight_decay"],
                                optimizer="adamw" if self.optimizer._decoupled else "adam",
-                               world_size=self.world_size,
+                               world_size=self.world_size, rank=self.rank,
+                               deterministic=bool(self.cfg.get("deterministic", False)),
+                               item_exchange=self.cfg.get("item_exchange", "all_reduce"),
                                state=dict(mU=sU["exp_avg"][lo:hi], vU=sU["exp_avg_sq"][lo:hi], mI=sI["exp_avg"],
                                           vI=sI["exp_avg_sq"], t=sU["step"]))
         self._step_bound = bound
