@@ -208,6 +208,17 @@ class MFTrainer(BaseTrainer):
                         lo, hi = self.shard.bounds(r)
                         if hi > lo:
                             _dist().broadcast(st[name][lo:hi], src=r)
+            if self.cfg.get("item_exchange", "all_reduce") == "reduce_scatter":
+                # the item moments of a rank are current on its slice of the item rows only
+                from ..user_shard import ItemSlices
+                I = self.model.item_embedding.weight
+                sti = self.optimizer.state.get(I, {})
+                for name in ("exp_avg", "exp_avg_sq"):
+                    if name in sti:
+                        for r in range(self.world_size):
+                            sl = ItemSlices(self.num_items, self.world_size, r)
+                            if sl.hi > sl.lo:
+                                _dist().broadcast(sti[name][sl.lo:sl.hi], src=r)
             if self.rank == 0:
                 super().save_checkpoint(path, **extra)
             _dist().barrier()
