@@ -61,6 +61,10 @@ def test_spmm_matches_scipy(device, d):
     acc = torch.from_numpy(X).to(device).clone()
     engine.spmm_csr(graph, torch.from_numpy(X).to(device), out=acc, accumulate=True)
     np.testing.assert_allclose(acc.cpu().numpy(), L @ X + X, rtol=1e-4, atol=1e-5)
+    for dd in (16, 32, 64, 128):                                  # the sliced form at every width (1, 1, 2, 4 slices)
+        xs = torch.randn(graph.n, dd, device=device)
+        torch.testing.assert_close(engine.spmm_csr(graph, xs, form="sliced"), engine.spmm_csr(graph, xs, form="rows"),
+                                   rtol=1e-5, atol=1e-6)
     # all-light path (no heavy list) gives the same result
     g2 = LaplacianCSR.from_scipy(L, device, heavy_threshold=10 ** 9)
     assert g2.n_heavy == 0
@@ -300,4 +304,9 @@ def test_full_size_spmm_properties(device):
     torch.testing.assert_close(Lx, ref, rtol=1e-4, atol=1e-5)
     acc = y.clone()
     engine.spmm_csr(graph, x, out=acc, accumulate=True)
+    torch.testing.assert_close(acc, y + Lx, rtol=1e-5, atol=1e-5)
+    # the feature-sliced form (slices of 32 floats pinned per XCD, rows by falling degree) gives the same product
+    torch.testing.assert_close(engine.spmm_csr(graph, x, form="sliced"), Lx, rtol=1e-5, atol=1e-6)
+    acc = y.clone()
+    engine.spmm_csr(graph, x, out=acc, accumulate=True, form="sliced")
     torch.testing.assert_close(acc, y + Lx, rtol=1e-5, atol=1e-5)

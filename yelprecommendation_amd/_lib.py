@@ -36,6 +36,7 @@ SIGNATURES = {
     "yr_bpr_mf_pull_step": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _f,
                             _d, _d, _d, _d, _d, _d, _d, _int, _int, _p, _i64, _p, _p, _p, _p, _p],
     "yr_spmm_csr": [_p, _p, _p, _p, _p, _i64, _int, _int, _p, _i64, _int, _p],
+    "yr_spmm_csr_sliced": [_p, _p, _p, _p, _p, _i64, _int, _int, _p, _p],
     "yr_ngcf_score_fwd": [_p, _int, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _p, _p],
     "yr_ngcf_score_bwd": [_p, _p, _int, _p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p],
     "yr_ngcf_dense_fwd": [_p, _p, _p, _p, _i64, _int, _p, _p],

@@ -33,8 +33,8 @@ constexpr int kSpmmHeavyBlocks = 256;
 // latencies per round otherwise), and slots past the row end issue no row load at all.
 template <int D>
 __device__ __forceinline__ void spmm_accumulate(const int32_t* __restrict__ col, const float* __restrict__ val,
-                                                const float* __restrict__ X, int lo, int hi, int first, int step,
-                                                int l, float4& acc) {
+                                                const float* __restrict__ Xl /* X + this lane's 4 floats */, int lo,
+                                                int hi, int first, int step, float4& acc) {
   int c[kSpmmUnroll];
   float w[kSpmmUnroll];
 #pragma unroll
@@ -50,7 +50,7 @@ __device__ __forceinline__ void spmm_accumulate(const int32_t* __restrict__ col,
 #pragma unroll
     for (int q = 0; q < kSpmmUnroll; ++q) {
       wc[q] = w[q];
-      r[q] = c[q] >= 0 ? ngcf_ld4(X + (int64_t)c[q] * D + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
+      r[q] = c[q] >= 0 ? ngcf_ld4(Xl + (int64_t)c[q] * D) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int nbase = base + step * kSpmmUnroll;
 #pragma unroll
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int32_t* __restr
     for (int h = blockIdx.x; h < n_heavy; h += kSpmmHeavyBlocks) {
       const int row = heavy[h];
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      spmm_accumulate<D>(col, val, X, rowptr[row], rowptr[row + 1], wave * GPW + grp, kWavesPerBlock * GPW, l, acc);
+      spmm_accumulate<D>(col, val, X + 4 * l, rowptr[row], rowptr[row + 1], wave * GPW + grp, kWavesPerBlock * GPW, acc);
 #pragma unroll
       for (int m = LPR; m < kWave; m <<= 1) {
         acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int32_t* __restr
       const int lo = rowptr[row], hi = rowptr[row + 1];
       if (hi - lo > heavy_t) continue;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      spmm_accumulate<D>(col, val, X, lo, hi, grp, GPW, l, acc);
+      spmm_accumulate<D>(col, val, X + 4 * l, lo, hi, grp, GPW, acc);
 #pragma unroll
       for (int m = LPR; m < kWave; m <<= 1) {
         acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
@@ -121,6 +121,62 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int32_t* __restr
       }
       if (grp == 0) {
         float* dst = Y + (int64_t)row * D + 4 * l;
+        if (ACCUM) {
+          const float4 old = ngcf_ld4(dst);
+          acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
+        }
+        *reinterpret_cast<float4*>(dst) = acc;
+      }
+    }
+  }
+}
+
+// Feature-sliced form: the row-per-wave kernel above gathers 256-byte rows out of an 8-10 MB half table
+// that no XCD's 4 MiB L2 holds (measured: 52 % L2 hits, 7x the algorithmic bytes at the fabric).  Here the
+// D floats of a row are cut into slices of 16 (64 bytes); the workgroups of one XCD (equal
+// blockIdx.x % 8 — a placement label: a different placement costs L2 hits, never correctness) work on
+// ONE slice, so the slice of the gathered half table (38 k rows x 64 B = 2.4 MB) stays in that XCD's L2
+// after first touch.  A wave owns a row of its slice: 16 lane groups of 4 lanes = 16 neighbours per pass,
+// kSlicedUnroll passes in flight.  Rows are visited in `row_order` (each half by falling degree: the long
+// rows start first), every XCD runs through the user half and then the item half.
+#ifndef YR_SLICE_WIDTH
+#define YR_SLICE_WIDTH 32
+#endif
+constexpr int kSliceWidth = YR_SLICE_WIDTH;        // floats per slice (32: one 128-byte line per gathered row slice;
+                                                   // 16 was measured slower: twice the cache-line requests per byte)
+
+template <int D, bool ACCUM>
+__global__ __launch_bounds__(kBlock) void spmm_csr_sliced_kernel(const int32_t* __restrict__ rowptr,
+                                                                 const int32_t* __restrict__ col,
+                                                                 const float* __restrict__ val,
+                                                                 const float* __restrict__ X, float* __restrict__ Y,
+                                                                 int n, const int32_t* __restrict__ row_order) {
+  constexpr int SW = D < kSliceWidth ? D : kSliceWidth;
+  constexpr int NS = D / SW;                      // slices: 1, 2, 4
+  constexpr int XPS = 8 / NS;                     // workgroup classes per slice
+  constexpr int LG = SW / 4;                      // lanes per group (one slice of a row)
+  constexpr int GPW = kWave / LG;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int grp = lane / LG, l = lane % LG;
+  const int cls = blockIdx.x & 7, slice = cls % NS, part = cls / NS;
+  const int cb = blockIdx.x >> 3;                 // workgroup number inside its class
+  const float* Xl = X + slice * SW + 4 * l;
+  const int out_off = slice * SW + 4 * l;
+  {
+    const int gw = cb * kWavesPerBlock + wave;
+    const int nw = (gridDim.x >> 3) * kWavesPerBlock;
+    for (int i = gw * XPS + part; i < n; i += nw * XPS) {
+      const int row = row_order ? row_order[i] : i;
+      const int lo = rowptr[row], hi = rowptr[row + 1];
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      spmm_accumulate<D>(col, val, Xl, lo, hi, grp, GPW, acc);
+#pragma unroll
+      for (int m = LG; m < kWave; m <<= 1) {
+        acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
+        acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
+      }
+      if (grp == 0) {
+        float* dst = Y + (int64_t)row * D + out_off;
         if (ACCUM) {
           const float4 old = ngcf_ld4(dst);
           acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
@@ -531,6 +587,29 @@ extern "C" int yr_spmm_csr(const int32_t* rowptr, const int32_t* col, const floa
   } else {
     YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_csr_kernel<kD, false>), dim3(grid), dim3(kBlock), 0, s, rowptr, col,
                                            val, X, Y, (int)n, heavy_rows, (int)n_heavy, heavy_threshold));
+  }
+  return launch_status();
+}
+
+extern "C" int yr_spmm_csr_sliced(const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
+                                  float* Y, int64_t n, int D, int accumulate, const int32_t* row_order,
+                                  void* stream) {
+  if (n < 0 || n > 0x7fffffff) return YR_ERR_BADARG;
+  if (n == 0) return 0;
+  if (!rowptr || !X || !Y || X == Y) return YR_ERR_BADARG;
+  // eight workgroup classes (one per XCD); one (row, slice) per wave while that stays below 2^19
+  // workgroups, the row loop covers larger graphs
+  const int sw = D < kSliceWidth ? D : kSliceWidth;
+  const int xps = 8 / (D / sw);
+  const int64_t per_class = (n + xps * kWavesPerBlock - 1) / (xps * kWavesPerBlock);
+  const int grid = 8 * (int)(per_class > 65536 ? 65536 : per_class);
+  hipStream_t s = (hipStream_t)stream;
+  if (accumulate) {
+    YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_csr_sliced_kernel<kD, true>), dim3(grid), dim3(kBlock), 0, s, rowptr,
+                                           col, val, X, Y, (int)n, row_order));
+  } else {
+    YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_csr_sliced_kernel<kD, false>), dim3(grid), dim3(kBlock), 0, s, rowptr,
+                                           col, val, X, Y, (int)n, row_order));
   }
   return launch_status();
 }

@@ -201,7 +201,13 @@ def triplet_sample(row_user, row_item, avoid_ptr, avoid_idx, num_users, num_item
     return tuple(out)
 
 
-def spmm_csr(graph, X, out=None, accumulate=False):
+# "rows": one wave per output row (default: the faster form on MI355X at Yelp2018 size, 76 us per launch);
+# "sliced": feature slices pinned per XCD — half the fabric traffic (425 -> 217 MB, L2 hits 52 -> 76 %) but
+# 80-89 us: the product is bound by the three dependent loads per short row, not by bytes
+SPMM_FORM = "rows"
+
+
+def spmm_csr(graph, X, out=None, accumulate=False, form=None):
     """Y = L X (or Y += L X) with L a :class:`yelprecommendation_amd.graph.LaplacianCSR`
     (reference models/ngcf.py:64,67: torch.sparse.mm(L, E))."""
     lib = _lib.load()
@@ -212,6 +218,15 @@ def spmm_csr(graph, X, out=None, accumulate=False):
         if accumulate:
             raise EngineError("accumulate needs an output buffer")
         out = torch.empty_like(X)
+    form = form or SPMM_FORM
+    if form not in ("rows", "sliced"):
+        raise EngineError("form must be 'rows' or 'sliced'")
+    if form == "sliced":
+        check(lib.yr_spmm_csr_sliced(_dev(graph.rowptr, torch.int32, "rowptr"), _dev(graph.col, torch.int32, "col"),
+                                     _dev(graph.val, torch.float32, "val"), _dev(X, torch.float32, "X"),
+                                     _dev(out, torch.float32, "Y"), n, d, 1 if accumulate else 0,
+                                     _opt(graph.row_order, torch.int32, "row_order"), _stream()), "yr_spmm_csr_sliced")
+        return out
     check(lib.yr_spmm_csr(_dev(graph.rowptr, torch.int32, "rowptr"), _dev(graph.col, torch.int32, "col"),
                           _dev(graph.val, torch.float32, "val"), _dev(X, torch.float32, "X"),
                           _dev(out, torch.float32, "Y"), n, d, 1 if accumulate else 0,

@@ -16,7 +16,7 @@ HEAVY_THRESHOLD = 256
 
 
 class LaplacianCSR:
-    def __init__(self, rowptr, col, val, n, device, heavy_threshold=HEAVY_THRESHOLD, symmetric=None):
+    def __init__(self, rowptr, col, val, n, device, heavy_threshold=HEAVY_THRESHOLD, symmetric=None, split=None):
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
         if rowptr.shape[0] != n + 1 or rowptr[-1] >= 2 ** 31:
             raise ValueError("bad rowptr")
@@ -30,13 +30,19 @@ class LaplacianCSR:
         self.val = torch.from_numpy(np.ascontiguousarray(val, dtype=np.float32)).to(device)
         self.heavy_rows = torch.from_numpy(heavy).to(device) if self.n_heavy else None
         self.symmetric = symmetric
+        # visiting order of the sliced SpMM: rows by falling degree (the longest rows start first); when the
+        # bipartite split is known (``split`` = number of user nodes, which come first), each half on its
+        # own, so that all workgroups gather from one half table at a time
+        split = int(split) if split is not None and 0 < int(split) < n else n
+        order = np.concatenate([np.argsort(-deg[:split], kind="stable"), split + np.argsort(-deg[split:], kind="stable")])
+        self.row_order = torch.from_numpy(order.astype(np.int32)).to(device)
 
     @classmethod
-    def from_scipy(cls, mat, device, heavy_threshold=HEAVY_THRESHOLD):
+    def from_scipy(cls, mat, device, heavy_threshold=HEAVY_THRESHOLD, split=None):
         mat = mat.tocsr()
         mat.sort_indices()
         sym = bool(abs(mat - mat.T).max() <= 1e-6 * max(abs(mat).max(), 1e-30)) if mat.nnz else True
-        return cls(mat.indptr, mat.indices, mat.data, mat.shape[0], device, heavy_threshold, sym)
+        return cls(mat.indptr, mat.indices, mat.data, mat.shape[0], device, heavy_threshold, sym, split)
 
     @classmethod
     def from_torch_sparse(cls, L: torch.Tensor, device=None, heavy_threshold=HEAVY_THRESHOLD):
@@ -54,7 +60,7 @@ class LaplacianCSR:
                           heavy_threshold=HEAVY_THRESHOLD):
         """Straight from the TSV columns, no dense (N, N) temporary; see :func:`laplacian_scipy`."""
         return cls.from_scipy(laplacian_scipy(user_id, item_id, rating, num_users, num_items), device,
-                              heavy_threshold)
+                              heavy_threshold, split=num_users)
 
     def to_torch_sparse(self):
         """Back to the reference's representation (sparse COO, float32)."""
