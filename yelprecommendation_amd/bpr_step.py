@@ -41,7 +41,7 @@ IMPL_NAMES = {
 class BPRMFStep:
     def __init__(self, U, I, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, optimizer="adam",
                  world_size=1, process_group=None, time_kernels=False, impl="auto", max_batch=0,
-                 state=None, split_item_update=False, item_chunks=2, item_exchange="all_reduce", rank=0,
+                 state=None, split_item_update=False, item_chunks=1, item_exchange="all_reduce", rank=0,
                  deterministic=False):
         """``state``: optional dict with pre-existing Adam tensors ``mU, vU, mI, vI`` (shared, updated
         in place) and the step count ``t`` — lets a trainer keep its torch-style optimizer state

@@ -96,9 +96,15 @@ template <int D>
 struct PullGeom {
   static_assert(D == 16 || D == 32 || D == 64 || D == 128, "unsupported width");
   static constexpr int LPR = D / 4;              // lanes per row (float4 each)
-  static constexpr int GPW = kWave / LPR;        // lane groups (= rows, = contributions per pass) per wave
-  static constexpr int R = kWavesPerBlock * GPW; // rows per bucket = 1024 / D
+  static constexpr int GPW = kWave / LPR;        // lane groups (= contributions per pass) per wave
+  static constexpr int R = kWavesPerBlock * GPW; // rows per bucket = 1024 / D (a wave owns GPW rows)
 };
+// A table with few rows and many contributions per row (a rank's user shard of an 8-GPU run: 3,959 rows,
+// 133 triplets per row and step) would leave most CUs without a bucket: then a wave owns ONE row and a
+// bucket is 4 rows (kNarrowRows), four times the workgroups.
+constexpr int kNarrowRows = kWavesPerBlock;
+constexpr int kNarrowShift = 2;
+constexpr int kNarrowBelow = 768;                // ... when there would be fewer 1024/D-row buckets than this
 
 inline int bucket_shift(int D) { return D == 16 ? 6 : D == 32 ? 5 : D == 64 ? 4 : 3; }
 
@@ -108,13 +114,15 @@ inline int bucket_shift(int D) { return D == 16 ? 6 : D == 32 ? 5 : D == 64 ? 4 
 template <int PT>
 __global__ __launch_bounds__(kPartThreads) void tile_partition_kernel(
     const int64_t* __restrict__ user, const int64_t* __restrict__ pos, const int64_t* __restrict__ neg, int64_t B,
-    int64_t nU, int64_t nI, int shift, int nbU, int nbI, int32_t* __restrict__ offU, int32_t* __restrict__ offI,
+    int64_t nU, int64_t nI, int shiftU, int shiftI, int nbU, int nbI, int32_t* __restrict__ offU,
+    int32_t* __restrict__ offI,
     int4* __restrict__ rec, int2* __restrict__ occ, int32_t* __restrict__ err_flag) {
   extern __shared__ int32_t s_cnt[];            // [nb + 1]
   __shared__ int s_wave[kPartThreads / kWave];
   constexpr int TILE = kPartThreads * PT;
   const int side = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
   const int nb = side ? nbI : nbU;
+  const int shift = side ? shiftI : shiftU;
   const int rmask = (1 << shift) - 1;
 
   int32_t u[PT], p[PT], n[PT];
@@ -382,10 +390,12 @@ __device__ __forceinline__ void walk_stream(const OwnerArgs& a, const unsigned s
   if (!HEAVY) sums.book(cur_row >= 0, cur_row - row_base, cur, grp);
 }
 
-template <int D, bool USER, bool FUSE_ADAM, bool DET>
+template <int D, bool USER, bool FUSE_ADAM, bool DET, bool ONEROW = false>
 __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(OwnerArgs a) {
   using G = PullGeom<D>;
-  constexpr int R = G::R, LPR = G::LPR, GPW = G::GPW;
+  constexpr int LPR = G::LPR, GPW = G::GPW;
+  constexpr int RPW = ONEROW ? 1 : GPW;          // rows a wave owns
+  constexpr int R = kWavesPerBlock * RPW;        // rows per bucket
   constexpr int CAP = USER ? kUserCap : kCap;    // records per chunk
   constexpr int PT = CAP / kBlock;
   __shared__ int s_pre[kTileGroup + 1];          // flattened start of every tile's segment
@@ -403,7 +413,8 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
   __shared__ int s_scan[kWavesPerBlock];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   const int grp = lane / LPR, l = lane % LPR;
-  const int row_l = wave * GPW + grp;            // the row this lane group finishes: GPW consecutive rows per wave
+  const int row_l = wave * RPW + (ONEROW ? 0 : grp);   // the row this lane group finishes (ONEROW: group 0 only)
+  const bool finisher = !ONEROW || grp == 0;
   float loss = 0.0f;
 #ifdef YR_STAMPS
   bool first_bucket = true;
@@ -412,9 +423,9 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
 
   for (int k = a.bucket_begin + blockIdx.x; k < a.bucket_end; k += gridDim.x) {
     const int row_f = k * R + row_l;
-    const bool valid_f = row_f < a.rows;
+    const bool valid_f = finisher && row_f < a.rows;
     const uint32_t o_f = (uint32_t)(row_f * D + 4 * l);
-    if (USER) s_own[row_l * LPR + l] = valid_f ? ld4o(a.own_old, o_f) : zero4();
+    if (USER && finisher) s_own[row_l * LPR + l] = valid_f ? ld4o(a.own_old, o_f) : zero4();
     YR_STAMP(1);
     RowSums<LPR, GPW> sums;
     sums.clear();
@@ -557,8 +568,8 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
         // light rows: wave w walks the records of ITS rows [w GPW, (w+1) GPW), one per lane group and step
         {
           float4 cur = zero4();
-          walk_stream<D, USER, false>(a, s_idx, s_x, s_y, s_z, s_own, s_light[wave * GPW], s_light[wave * GPW + GPW], grp,
-                                      GPW, wave * GPW, grp, l, sums, cur, loss);
+          walk_stream<D, USER, false>(a, s_idx, s_x, s_y, s_z, s_own, s_light[wave * RPW], s_light[wave * RPW + RPW], grp,
+                                      GPW, wave * RPW, grp, l, sums, cur, loss);
         }
         // heavy rows of the chunk: all waves on one row, partial sums combined in wave order
         if ((cend - c0) - s_light[kWave] > 0) {   // workgroup-uniform
@@ -573,7 +584,7 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
             cross_group_sum<LPR>(t);
             if (grp == 0) s_heavy[wave][l] = t;
             __syncthreads();
-            if (row_l == r) {
+            if (finisher && row_l == r) {
 #pragma unroll
               for (int w = 0; w < kWavesPerBlock; ++w) {
                 const float4 h = s_heavy[w][l];
@@ -647,7 +658,7 @@ __global__ __launch_bounds__(kBlock) void pull_loss_finalize_kernel(const float*
 // --------------------------------------------------------------------------- host side
 // How a batch of B triplets is cut into tiles, and the workspace carve-up (all 16-byte aligned).
 struct PullPlan {
-  int pt, tile, T, shift, nbU, nbI;
+  int pt, tile, T, shiftU, shiftI, narrow_users, nbU, nbI;
   size_t o_offU, o_offI, o_rec, o_occ, o_coeff, bytes;
 };
 
@@ -663,9 +674,13 @@ inline int tile_pt(int64_t B) {
 
 inline PullPlan make_plan(int64_t B, int64_t nU, int64_t nI, int D, bool upper_bound) {
   PullPlan p;
-  p.shift = bucket_shift(D);
-  const int R = 1 << p.shift;
-  p.nbU = (int)((nU + R - 1) / R);
+  p.shiftI = bucket_shift(D);
+  const int R = 1 << p.shiftI;
+  // user buckets of 4 rows (a wave per row) when buckets of 1024/D rows would leave most of the 2,048
+  // resident owner workgroups without work (user shards of a multi-GPU run, small tables)
+  p.narrow_users = (nU + R - 1) / R < kNarrowBelow && R > kNarrowRows;
+  p.shiftU = p.narrow_users ? kNarrowShift : p.shiftI;
+  p.nbU = (int)((nU + (1 << p.shiftU) - 1) >> p.shiftU);
   p.nbI = (int)((nI + R - 1) / R);
   p.pt = tile_pt(B);
   p.tile = kPartThreads * p.pt;
@@ -693,8 +708,8 @@ static int pull_check_common(int64_t B, int D, int64_t num_users, int64_t num_it
   if (D != 16 && D != 32 && D != 64 && D != 128) return YR_ERR_UNSUPPORTED;
   // the partition's LDS histogram holds one counter per bucket of 1024/D rows; user ids share a
   // word with the local item row
-  const int R = 1 << bucket_shift(D);
-  if ((num_users + R - 1) / R > kMaxBuckets || (num_items + R - 1) / R > kMaxBuckets) return YR_ERR_UNSUPPORTED;
+  const PullPlan pl = make_plan(0, num_users, num_items, D, false);
+  if (pl.nbU > kMaxBuckets || pl.nbI > kMaxBuckets) return YR_ERR_UNSUPPORTED;
   if (num_users > kOccMask) return YR_ERR_UNSUPPORTED;
   if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return YR_ERR_BADARG;
   if ((int64_t)make_plan(B, num_users, num_items, D, false).bytes > workspace_bytes) return YR_ERR_BADARG;
@@ -734,7 +749,7 @@ extern "C" int yr_bpr_mf_pull_index(const int64_t* user, const int64_t* pos, con
 #define YR_PART_CASE(PT)                                                                                         \
   case PT:                                                                                                       \
     hipLaunchKernelGGL((tile_partition_kernel<PT>), grid, dim3(kPartThreads), lds, s, user, pos, neg, B, num_users, \
-                       num_items, p.shift, p.nbU, p.nbI, offU, offI, rec, occ, err_flag);                        \
+                       num_items, p.shiftU, p.shiftI, p.nbU, p.nbI, offU, offI, rec, occ, err_flag);                        \
     break
   switch (p.pt) {
     YR_PART_CASE(1);
@@ -781,7 +796,11 @@ static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU
     ua.bucket_begin = 0; ua.bucket_end = p.nbU;
     ua.heavy_t = kHeavyRow; ua.inv_batch = inv_batch; ua.adam = adam;
     const int gu = p.nbU < YR_LOSS_PARTIALS ? p.nbU : YR_LOSS_PARTIALS;   // one loss-partial slot per workgroup
-    if (deterministic)
+    if (p.narrow_users && deterministic)
+      hipLaunchKernelGGL((owner_pass_kernel<D, true, true, true, true>), dim3(gu), dim3(kBlock), 0, s, ua);
+    else if (p.narrow_users)
+      hipLaunchKernelGGL((owner_pass_kernel<D, true, true, false, true>), dim3(gu), dim3(kBlock), 0, s, ua);
+    else if (deterministic)
       hipLaunchKernelGGL((owner_pass_kernel<D, true, true, true>), dim3(gu), dim3(kBlock), 0, s, ua);
     else
       hipLaunchKernelGGL((owner_pass_kernel<D, true, true, false>), dim3(gu), dim3(kBlock), 0, s, ua);

@@ -132,7 +132,8 @@ def pull_supported(num_users, num_items, d):
     if d not in SUPPORTED_WIDTHS:
         return False
     r = pull_bucket_rows(d)
-    return (-(-num_users // r) <= PULL_MAX_BUCKETS and -(-num_items // r) <= PULL_MAX_BUCKETS
+    ru = 4 if (-(-num_users // r) < 768 and r > 4) else r       # few user rows: buckets of 4 rows (csrc/bpr_pull.hip)
+    return (-(-num_users // ru) <= PULL_MAX_BUCKETS and -(-num_items // r) <= PULL_MAX_BUCKETS
             and num_users <= PULL_MAX_USERS)
 
 
