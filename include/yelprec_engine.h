@@ -333,7 +333,8 @@ int yr_mf_eval_topk(const float *U, const float *I, const int64_t *users, int64_
  *     out[r, 0..k) = the k best column ids, score descending, id ascending on ties
  * mask_value = -3.40282e+38 reproduces `pred[mask_items] = -3.40282e+38`; 0 reproduces
  * CDAE's `pred * logical_not(input_mask)`.  mask_ptr may be NULL (no mask).  k <= 64.
- * Rows shorter than k are padded with -1.  `scores` is not modified.
+ * Rows shorter than k are padded with -1.  `scores` is not modified.  ncols <= 2^19 - 2048 (the row's
+ * mask bitmap lives in LDS; YR_ERR_UNSUPPORTED beyond).
  * mask_rows (may be NULL): row r's mask list is CSR row mask_rows[r] instead of r.
  * replaces: numpy fancy-index store + argpartition + take_along_axis + argsort per user.
  * ------------------------------------------------------------------------- */

@@ -104,7 +104,10 @@ struct PullGeom {
 // bucket is 4 rows (kNarrowRows), four times the workgroups.
 constexpr int kNarrowRows = kWavesPerBlock;
 constexpr int kNarrowShift = 2;
-constexpr int kNarrowBelow = 768;                // ... when there would be fewer 1024/D-row buckets than this
+#ifndef YR_NARROW_BELOW
+#define YR_NARROW_BELOW 768
+#endif
+constexpr int kNarrowBelow = YR_NARROW_BELOW;                // ... when there would be fewer 1024/D-row buckets than this
 
 inline int bucket_shift(int D) { return D == 16 ? 6 : D == 32 ? 5 : D == 64 ? 4 : 3; }
 

@@ -137,7 +137,9 @@ extern "C" int yr_topk_masked(const float* scores, int64_t nrows, int64_t ncols,
                               const int64_t* mask_ptr, const int64_t* mask_idx, const int64_t* mask_rows,
                               float mask_value, int k, int64_t* out, void* stream) {
   if (nrows < 0 || ncols <= 0 || k <= 0 || k > 64 || row_stride < ncols) return YR_ERR_BADARG;
-  if (ncols > (int64_t)1 << 20) return YR_ERR_UNSUPPORTED;          // LDS bitmap: 128 KiB at 2^20 columns
+  // the mask bitmap of a row lives in dynamic LDS (ncols / 8 bytes): 64 KiB without raising the launch
+  // attribute, less the static 132 bytes -> at most 2^19 - 2^11 columns (no silent HIP launch error beyond)
+  if (ncols > ((int64_t)1 << 19) - 2048) return YR_ERR_UNSUPPORTED;
   if (nrows == 0) return 0;
   if (!scores || !out || (mask_ptr && !mask_idx)) return YR_ERR_BADARG;
   const size_t lds = (size_t)((ncols + 31) / 32) * sizeof(uint32_t);
