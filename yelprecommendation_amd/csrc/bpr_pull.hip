@@ -102,6 +102,10 @@ struct PullGeom {
 // A table with few rows and many contributions per row (a rank's user shard of an 8-GPU run: 3,959 rows,
 // 133 triplets per row and step) would leave most CUs without a bucket: then a wave owns ONE row and a
 // bucket is 4 rows (kNarrowRows), four times the workgroups.
+#ifndef YR_MIN_TILES
+#define YR_MIN_TILES 64
+#endif
+constexpr int kMinTiles = YR_MIN_TILES;
 constexpr int kNarrowRows = kWavesPerBlock;
 constexpr int kNarrowShift = 2;
 #ifndef YR_NARROW_BELOW
@@ -119,9 +123,10 @@ __global__ __launch_bounds__(kPartThreads) void tile_partition_kernel(
     const int64_t* __restrict__ user, const int64_t* __restrict__ pos, const int64_t* __restrict__ neg, int64_t B,
     int64_t nU, int64_t nI, int shiftU, int shiftI, int nbU, int nbI, int32_t* __restrict__ offU,
     int32_t* __restrict__ offI,
-    int4* __restrict__ rec, int2* __restrict__ occ, int32_t* __restrict__ err_flag) {
-  extern __shared__ int32_t s_cnt[];            // [nb + 1]
+    int4* __restrict__ rec, int2* __restrict__ occ, int32_t* __restrict__ err_flag, int stage_off) {
+  extern __shared__ int32_t s_cnt[];            // [nb + 1] bucket counters, then (16-byte aligned) the staged tile
   __shared__ int s_wave[kPartThreads / kWave];
+  int4* s_stage = reinterpret_cast<int4*>(s_cnt + stage_off);   // TILE records of 16 B, or 2 TILE of 8 B
   constexpr int TILE = kPartThreads * PT;
   const int side = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
   const int nb = side ? nbI : nbU;
@@ -186,24 +191,34 @@ __global__ __launch_bounds__(kPartThreads) void tile_partition_kernel(
   __syncthreads();
   int32_t* off = (side ? offI : offU) + (int64_t)tile * (nb + 1);
   for (int i = tid; i <= nb; i += kPartThreads) off[i] = s_cnt[i];
+  // The records are first placed bucket by bucket in LDS and then written out with 16-byte coalesced
+  // stores: scattering them straight to global memory (8/16 bytes per lane to 64 different lines per wave
+  // instruction) was bound by the request rate of the L2, not by bytes.
+  const int total = s_cnt[nb];
   if (side == 0) {
-    int4* out = rec + (int64_t)tile * TILE;
 #pragma unroll
     for (int k = 0; k < PT; ++k)
       if (u[k] >= 0) {
         const int b = tile * TILE + k * kPartThreads + tid;
-        out[s_cnt[u[k] >> shift] + ra[k]] = make_int4(p[k], n[k], b, u[k] & rmask);
+        s_stage[s_cnt[u[k] >> shift] + ra[k]] = make_int4(p[k], n[k], b, u[k] & rmask);
       }
     if (bad && err_flag) atomicOr(err_flag, bad);
+    __syncthreads();
+    int4* out = rec + (int64_t)tile * TILE;
+    for (int i = tid; i < total; i += kPartThreads) out[i] = s_stage[i];
   } else {
-    int2* out = occ + (int64_t)tile * TILE * 2;
+    int2* stage2 = reinterpret_cast<int2*>(s_stage);
 #pragma unroll
     for (int k = 0; k < PT; ++k)
       if (u[k] >= 0) {
         const int b = tile * TILE + k * kPartThreads + tid;
-        out[s_cnt[p[k] >> shift] + ra[k]] = make_int2(u[k] | ((p[k] & rmask) << kOccShift), b);
-        out[s_cnt[n[k] >> shift] + rb[k]] = make_int2(u[k] | ((n[k] & rmask) << kOccShift), b | (int)0x80000000);
+        stage2[s_cnt[p[k] >> shift] + ra[k]] = make_int2(u[k] | ((p[k] & rmask) << kOccShift), b);
+        stage2[s_cnt[n[k] >> shift] + rb[k]] = make_int2(u[k] | ((n[k] & rmask) << kOccShift), b | (int)0x80000000);
       }
+    __syncthreads();
+    int4* out = reinterpret_cast<int4*>(occ + (int64_t)tile * TILE * 2);   // two occurrences per 16 bytes
+    const int n16 = (total + 1) >> 1;
+    for (int i = tid; i < n16; i += kPartThreads) out[i] = s_stage[i];
   }
 }
 
@@ -667,11 +682,11 @@ struct PullPlan {
 
 inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-// tiles of 8192 triplets, halved while there would be fewer than 32 of them (the partition launch
+// tiles of 4096 triplets, halved while there would be fewer than kMinTiles of them (the partition launch
 // and the owners' segment runs both want tiles that are neither too few nor too small)
 inline int tile_pt(int64_t B) {
-  int pt = 8;
-  while (pt > 1 && (B + (int64_t)kPartThreads * pt - 1) / ((int64_t)kPartThreads * pt) < 32) pt >>= 1;
+  int pt = 4;                                    // a staged tile of 4096 triplets is 64 KB of LDS
+  while (pt > 1 && (B + (int64_t)kPartThreads * pt - 1) / ((int64_t)kPartThreads * pt) < kMinTiles) pt >>= 1;
   return pt;
 }
 
@@ -688,9 +703,9 @@ inline PullPlan make_plan(int64_t B, int64_t nU, int64_t nI, int D, bool upper_b
   p.pt = tile_pt(B);
   p.tile = kPartThreads * p.pt;
   p.T = (int)((B + p.tile - 1) / p.tile);
-  // upper bound over every batch size <= B (workspace sizing): T < 64 whenever pt < 8
-  const int64_t T = upper_bound ? ((B + 8191) / 8192 > 64 ? (B + 8191) / 8192 : 64) : p.T;
-  const int64_t slots = upper_bound ? B + 8192 : (int64_t)p.T * p.tile;
+  // upper bound over every batch size <= B (workspace sizing): T < 2 kMinTiles whenever pt < 4
+  const int64_t T = upper_bound ? ((B + 4095) / 4096 > 2 * kMinTiles ? (B + 4095) / 4096 : 2 * kMinTiles) : p.T;
+  const int64_t slots = upper_bound ? B + 4096 : (int64_t)p.T * p.tile;
   size_t o = 0;
   p.o_offU = o; o += align16((size_t)T * (p.nbU + 1) * 4);
   p.o_offI = o; o += align16((size_t)T * (p.nbI + 1) * 4);
@@ -746,19 +761,27 @@ extern "C" int yr_bpr_mf_pull_index(const int64_t* user, const int64_t* pos, con
   int32_t* offI = (int32_t*)(w + p.o_offI);
   int4* rec = (int4*)(w + p.o_rec);
   int2* occ = (int2*)(w + p.o_occ);
-  const size_t lds = (size_t)((p.nbU > p.nbI ? p.nbU : p.nbI) + 1) * 4;
+  // dynamic LDS: the bucket counters, then the staged tile (16 B per triplet on either side)
+  const int stage_off = (((p.nbU > p.nbI ? p.nbU : p.nbI) + 1) + 3) & ~3;           // in ints, 16-byte aligned
+  const size_t lds = (size_t)stage_off * 4 + (size_t)p.tile * 16;
   const dim3 grid(p.T, 2);
   hipStream_t s = (hipStream_t)stream;
 #define YR_PART_CASE(PT)                                                                                         \
-  case PT:                                                                                                       \
+  case PT: {                                                                                                     \
+    static bool raised = false;                   /* more than the default 64 KB of dynamic LDS: once per process */ \
+    if (!raised && lds > 65536) {                                                                                \
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_partition_kernel<PT>),        \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);    \
+      if (e != hipSuccess) return (int)e;                                                                        \
+      raised = true;                                                                                             \
+    }                                                                                                            \
     hipLaunchKernelGGL((tile_partition_kernel<PT>), grid, dim3(kPartThreads), lds, s, user, pos, neg, B, num_users, \
-                       num_items, p.shiftU, p.shiftI, p.nbU, p.nbI, offU, offI, rec, occ, err_flag);                        \
-    break
+                       num_items, p.shiftU, p.shiftI, p.nbU, p.nbI, offU, offI, rec, occ, err_flag, stage_off);  \
+  } break
   switch (p.pt) {
     YR_PART_CASE(1);
     YR_PART_CASE(2);
     YR_PART_CASE(4);
-    YR_PART_CASE(8);
     default: return YR_ERR_BADARG;
   }
 #undef YR_PART_CASE
