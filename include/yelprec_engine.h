@@ -417,6 +417,29 @@ int yr_negative_mask(const float *positives, int64_t B, int64_t num_items, int n
                      float *out, int32_t *err_flag, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Sparse-input form of the CDAE encoder   (reference models/cdae.py:43-49; SURVEY 2.1: the input rows are
+ *   ~0.1 % dense): z = act_h(W_h . dropout_p(x) + b_h + V[u]) and dW_h = dz^T . dropout_p(x) over the
+ *   non-zeros only, instead of two GEMMs over K = num_items.
+ * yr_cdae_compact_rows: the non-zeros of dropout_p(x[B, I]) as (column, value) lists in ascending column
+ *   order, 32 sub-lists per row (one per range of cpp = yr_cdae_sparse_part_columns(I) columns):
+ *   cols / vals [B, 32, cpp], count [B, 32] — sized for the worst case, nothing can overflow.  p = 0: no
+ *   dropout; p > 0: the mask yr_dropout_seeded(seed) applies, scale 1/(1-p) — no dense corrupted copy of
+ *   x is written.
+ * yr_cdae_sparse_encode: z[B, H] from the lists, W_h [H, I], b_h [H], V [num_users, H], user [B];
+ *   act 0 identity / 1 sigmoid (bias, user-node add and activation fused).
+ * yr_cdae_sparse_dwh: dWh [H, I] += dz^T . lists (dWh zeroed by the caller; float atomics).
+ * ------------------------------------------------------------------------- */
+int64_t yr_cdae_sparse_part_columns(int64_t I);
+int yr_cdae_compact_rows(const float *x, int64_t B, int64_t I, uint64_t seed, double p,
+                         int32_t *cols, float *vals, int32_t *count, void *stream);
+int yr_cdae_sparse_encode(const int32_t *cols, const float *vals, const int32_t *count,
+                          const float *Wh, const float *bh, const float *V, const int64_t *user,
+                          int64_t B, int64_t I, int H, int64_t num_users, int act, float *z,
+                          int32_t *err_flag, void *stream);
+int yr_cdae_sparse_dwh(const int32_t *cols, const float *vals, const int32_t *count,
+                       const float *dz, int64_t B, int64_t I, int H, float *dWh, void *stream);
+
+/* ---------------------------------------------------------------------------
  * Device-side BPR triplet stream   (reference train.py:76-77: DataLoader(MFDataset, shuffle=True);
  *   data/datasets/mf_dataset.py:18-32: __getitem__ + _negative_sampling)
  * Stream positions [first, first + count) of epoch `epoch`: position t reads row P(t) of

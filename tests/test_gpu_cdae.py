@@ -243,6 +243,47 @@ def test_config5_shape_step_matches_oracle(device, tmp_path):
         np.testing.assert_allclose(p.detach().cpu().numpy(), r, rtol=1e-3, atol=2e-6)
 
 
+def test_sparse_encoder_equals_dense_encoder(device, tmp_path):
+    """The sparse-input form of the encoder (row compaction with the dropout mask applied on the fly,
+    gather encoder, scatter dW_h) against the dense GEMM form on the same inputs: compacted rows ==
+    yr_dropout_seeded's output exactly, outputs and ALL parameter gradients equal to rounding; ragged
+    catalogue width, an all-zero row, a dense-ish row, duplicate users."""
+    from yelprecommendation_amd import engine
+    from yelprecommendation_amd.loss import NSBCELoss
+    from yelprecommendation_amd.models.cdae import CDAE
+    from yelprecommendation_amd.utils import make_config
+    rs = np.random.RandomState(6)
+    nu, ni, H, B = 70, 1503, 128, 37
+    x = (rs.rand(B, ni) < 0.03).astype(np.float32)
+    x[3] = 0.0
+    x[5] = (rs.rand(ni) < 0.6).astype(np.float32)
+    neg = ((rs.rand(B, ni) < 0.1) * (1 - x)).astype(np.float32)
+    users = rs.randint(0, nu, B).astype(np.int64); users[7] = users[2]
+    t = lambda a: torch.from_numpy(a).to(device)
+    for p, seed in ((0.0, 0), (0.6, 123456789012345)):
+        rows = engine.SparseRows(t(x), seed, p)
+        want = engine.dropout_seeded(t(x), seed, p) if p > 0 else t(x)
+        assert torch.equal(rows.to_dense(), want)                                  # same mask, same scale
+        cols = rows.row_columns(5)
+        assert bool((cols[1:] > cols[:-1]).all()) and rows.row_columns(3).numel() == 0   # ascending, empty row
+    grads = {}
+    for sparse in (True, False):
+        torch.manual_seed(11)
+        model = CDAE(make_config("CDAE", hidden_size=H, device="cuda", model_dir=str(tmp_path), sparse_encoder=sparse), ni, nu)
+        assert model.sparse_encoder == sparse
+        model.train()
+        torch.manual_seed(5)                                                       # same dropout seed draw
+        pred = model(t(users), t(x))
+        NSBCELoss()(pred, t(x), t(neg)).backward()
+        grads[sparse] = (pred.detach(), [q.grad.clone() for q in model.parameters()])
+        model.eval()
+        grads[sparse] += (model(t(users), t(x)).detach(),)
+    torch.testing.assert_close(grads[True][0], grads[False][0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(grads[True][2], grads[False][2], rtol=1e-5, atol=1e-6)
+    for a, b in zip(grads[True][1], grads[False][1]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-7 + 1e-5 * float(b.abs().max()))
+
+
 def test_device_batches_match_host_definitions(device):
     """yr_csr_rows_to_dense / yr_negative_mask behind data/cdae_batches.py: dense rows identical to
     the torch (CPU) construction; negative masks with the reference's law — exact count, never a

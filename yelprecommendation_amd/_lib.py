@@ -69,6 +69,10 @@ SIGNATURES = {
     "yr_csr_rows_to_dense": [_p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p],
     "yr_negative_mask": [_p, _i64, _i64, _int, C.c_uint64, _p, _p, _p],
     "yr_sgd_dense": [_p, _p, _i64, _d, _d, _int, _p],
+    "yr_cdae_sparse_part_columns": [_i64],
+    "yr_cdae_compact_rows": [_p, _i64, _i64, C.c_uint64, _d, _p, _p, _p, _p],
+    "yr_cdae_sparse_encode": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _int, _i64, _int, _p, _p, _p],
+    "yr_cdae_sparse_dwh": [_p, _p, _p, _p, _i64, _i64, _int, _p, _p],
     "yr_triplet_sample": [_p, _p, _i64, _p, _p, _i64, _i64, C.c_uint64, C.c_uint64, _int, _i64, _i64,
                           _p, _p, _p, _p, _p],
 }
@@ -107,6 +111,7 @@ def load():
         fn.restype = {"yr_engine_arch": C.c_char_p,
                       "yr_bpr_mf_pull_workspace_bytes": C.c_int64,
                       "yr_rank_metrics_workspace_bytes": C.c_int64,
+                      "yr_cdae_sparse_part_columns": C.c_int64,
                       "yr_mf_eval_topk_workspace_bytes": C.c_int64}.get(name, C.c_int)
     v = lib.yr_engine_version()
     if v != ENGINE_VERSION:

@@ -26,10 +26,11 @@ from .user_shard import ItemSlices, reduce_scatter_item_exchange, sharded_item_e
 
 
 # impl="auto": the pull form from this many triplets per rank and step upwards, the two-launch atomic
-# form below (measured on MI355X at Yelp2018 shape: 24 vs 39 us at 4,096, 34 vs 42 us at 16,384, 45.7 vs
-# 45.3 us at 32,768, 68 vs 53 us at 65,536); the choice is made from the GLOBAL batch so that every rank
-# of a sharded run takes the same form (the two forms issue different collectives)
-AUTO_PULL_MIN_BATCH = 32768
+# form below (measured on MI355X at Yelp2018 shape, atomic vs pull: 24 vs 37 us at 4,096, 35 vs 38 us at
+# 16,384, 40.9 vs 40.1 us at 24,576, 45 vs 42 us at 32,768, 68 vs 47 us at 65,536); the choice is made from
+# the GLOBAL batch so that every rank of a sharded run takes the same form (the two forms issue different
+# collectives)
+AUTO_PULL_MIN_BATCH = 24576
 
 IMPL_NAMES = {
     "auto": "auto: atomic scatter + one Adam launch below %d triplets per rank and step, pull above" % AUTO_PULL_MIN_BATCH,

@@ -355,6 +355,69 @@ def dropout(x, rnd, p):
     return out
 
 
+SPARSE_PARTS = 32       # csrc/cdae_sparse.hip kParts
+
+
+class SparseRows:
+    """(column, value) lists of the non-zeros of dropout_p(x), 32 sub-lists per row (csrc/cdae_sparse.hip);
+    the list buffers are sized for the worst case once per batch shape and reused by the next call."""
+    _pool = {}
+
+    def __init__(self, x, seed=0, p=0.0):
+        lib = _lib.load()
+        B, I = x.shape
+        self.cpp = int(lib.yr_cdae_sparse_part_columns(I))
+        key = (x.device, B, I)
+        buf = SparseRows._pool.get(key)
+        if buf is None:
+            n = B * SPARSE_PARTS * self.cpp
+            buf = (torch.empty(n, dtype=torch.int32, device=x.device), torch.empty(n, dtype=torch.float32, device=x.device))
+            SparseRows._pool = {key: buf}                  # one batch shape at a time
+        self.cols, self.vals = buf
+        self.count = torch.empty(B * SPARSE_PARTS, dtype=torch.int32, device=x.device)
+        self.B, self.I = B, I
+        check(lib.yr_cdae_compact_rows(_dev(x, torch.float32, "x"), B, I, int(seed) & (2**64 - 1), float(p),
+                                       self.cols.data_ptr(), self.vals.data_ptr(), self.count.data_ptr(), _stream()),
+              "yr_cdae_compact_rows")
+
+    def to_dense(self):
+        """The dense matrix the lists stand for (tests)."""
+        B, P, cpp = self.B, SPARSE_PARTS, self.cpp
+        out = torch.zeros(B, self.I, dtype=torch.float32, device=self.cols.device)
+        m = torch.arange(cpp, device=out.device)[None, :] < self.count[:, None]          # [B*P, cpp]
+        rows = torch.arange(B, device=out.device).repeat_interleave(P)[:, None].expand(-1, cpp)[m]
+        out[rows, self.cols.view(B * P, cpp)[m].long()] = self.vals.view(B * P, cpp)[m]
+        return out
+
+    def row_columns(self, r):
+        """Columns of row r in list order (tests)."""
+        c = self.cols.view(self.B, SPARSE_PARTS, self.cpp)[r]
+        n = self.count.view(self.B, SPARSE_PARTS)[r]
+        return torch.cat([c[q, :int(n[q])] for q in range(SPARSE_PARTS)])
+
+
+def cdae_sparse_encode(rows: "SparseRows", Wh, bh, V, user, act, err_flag=None):
+    """z = act(Wh . rows + bh + V[user])   (reference models/cdae.py:49, sparse input)."""
+    lib = _lib.load()
+    H = Wh.shape[0]
+    z = torch.empty(rows.B, H, dtype=torch.float32, device=Wh.device)
+    check(lib.yr_cdae_sparse_encode(rows.cols.data_ptr(), rows.vals.data_ptr(), rows.count.data_ptr(),
+                                    _dev(Wh, torch.float32, "Wh"), _dev(bh, torch.float32, "bh"),
+                                    _dev(V, torch.float32, "V"), _dev(user, torch.int64, "user"), rows.B, rows.I, H,
+                                    V.shape[0], int(act), z.data_ptr(), _opt(err_flag, torch.int32, "err_flag"),
+                                    _stream()), "yr_cdae_sparse_encode")
+    return z
+
+
+def cdae_sparse_dwh(rows: "SparseRows", dz, dWh):
+    """dWh += dz^T . rows (dWh [H, I] zeroed by the caller)."""
+    lib = _lib.load()
+    check(lib.yr_cdae_sparse_dwh(rows.cols.data_ptr(), rows.vals.data_ptr(), rows.count.data_ptr(),
+                                 _dev(dz, torch.float32, "dz"), rows.B, rows.I, dz.shape[1],
+                                 _dev(dWh, torch.float32, "dWh"), _stream()), "yr_cdae_sparse_dwh")
+    return dWh
+
+
 def sigmoid_(x):
     lib = _lib.load()
     check(lib.yr_sigmoid(_dev(x, torch.float32, "x"), x.numel(), _stream()), "yr_sigmoid")

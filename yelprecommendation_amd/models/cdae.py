@@ -59,6 +59,40 @@ class _CDAEForward(torch.autograd.Function):
         return None, None, None, None, None, dWh, dbh, dV, dWo, dbo
 
 
+class _CDAEForwardSparse(torch.autograd.Function):
+    """The same node with the encoder over the NON-ZEROS of the (corrupted) input only
+    (csrc/cdae_sparse.hip): row compaction with the dropout mask applied on the fly, gather-form encoder
+    with bias / user-node add / activation fused, scatter-form dW_h.  Mathematically the dense node
+    (the skipped terms are exact zeros); sums run in another order."""
+
+    @staticmethod
+    def forward(ctx, user_id, x, seed, p, hidden_act, output_act, err_flag, Wh, bh, V, Wo, bo):
+        user_id = user_id.contiguous()
+        rows = engine.SparseRows(x.contiguous(), seed, p)
+        Whd, Wod = Wh.detach(), Wo.detach()
+        z = engine.cdae_sparse_encode(rows, Whd, bh.detach(), V.detach(), user_id, hidden_act, err_flag=err_flag)
+        y = engine.gemm_f32(z, Wod, transB=True, bias=bo.detach(), act=output_act)
+        ctx.hidden_act, ctx.output_act, ctx.rows = hidden_act, output_act, rows
+        ctx.save_for_backward(user_id, z, y, Whd, Wod, V.detach())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        user_id, z, y, Wh, Wo, V = ctx.saved_tensors
+        dy = dy.contiguous()
+        g = engine.sigmoid_bwd(dy, y) if ctx.output_act == engine.ACT_SIGMOID else dy
+        dWo = engine.gemm_f32(g, z, transA=True)             # [I, H] = g^T z
+        dbo = engine.colsum(g)
+        dz = engine.gemm_f32(g, Wo, split_k=_split_k(g.shape[1]))       # [B, H] = g Wo
+        if ctx.hidden_act == engine.ACT_SIGMOID:
+            engine.sigmoid_bwd_(dz, z)
+        dWh = engine.cdae_sparse_dwh(ctx.rows, dz, torch.zeros_like(Wh))
+        dbh = engine.colsum(dz)
+        dV = torch.zeros_like(V)
+        engine.row_scatter_add(dz, user_id, dV)
+        return None, None, None, None, None, None, None, dWh, dbh, dV, dWo, dbo
+
+
 class CDAE(BaseModel):
 
     def __init__(self, cfg, num_items, num_users):
@@ -80,6 +114,8 @@ class CDAE(BaseModel):
         self.output_activation = self._activation_module(cfg.output_activation)
         self._hidden_act = _ACT[cfg.hidden_activation]
         self._output_act = _ACT[cfg.output_activation]
+        # encoder over the non-zeros of the input (default) or as a dense GEMM over the whole catalogue
+        self.sparse_encoder = bool(cfg.get("sparse_encoder", True)) if hasattr(cfg, "get") else True
         self._err_flag = None
         self._init_weights()
 
@@ -112,13 +148,26 @@ class CDAE(BaseModel):
         seed = int(torch.randint(0, 1 << 62, (1,)).item())
         return engine.dropout_seeded(x.contiguous(), seed, self.corruption_level)
 
+    def _params(self):
+        return (self.hidden_layer.weight, self.hidden_layer.bias, self.user_nodes.weight,
+                self.output_layer.weight, self.output_layer.bias)
+
     def encode_decode(self, user_id, x_in):
         """forward() on an already-corrupted input (used by tests that replay recorded masks)."""
-        return _CDAEForward.apply(user_id, x_in, self._hidden_act, self._output_act, self._flag(),
-                                  self.hidden_layer.weight, self.hidden_layer.bias, self.user_nodes.weight,
-                                  self.output_layer.weight, self.output_layer.bias)
+        if self.sparse_encoder:
+            return _CDAEForwardSparse.apply(user_id, x_in, 0, 0.0, self._hidden_act, self._output_act, self._flag(),
+                                            *self._params())
+        return _CDAEForward.apply(user_id, x_in, self._hidden_act, self._output_act, self._flag(), *self._params())
 
     def forward(self, user_id, x):
         # reference models/cdae.py:46-52 (`if self.train:` is always true there; nn.Dropout itself
         # follows train()/eval(), which add_noise reproduces)
+        if self.sparse_encoder and "add_noise" not in self.__dict__ and type(self).add_noise is CDAE.add_noise:
+            # the dropout mask of add_noise() is applied while the rows are compacted: same seed draw from
+            # torch's generator, same Philox words per position, no dense corrupted copy of x (an overridden
+            # add_noise — the tests replay recorded dropout outcomes through it — is honoured below)
+            p = self.corruption_level if self.training else 0.0
+            seed = int(torch.randint(0, 1 << 62, (1,)).item()) if p > 0 else 0
+            return _CDAEForwardSparse.apply(user_id, x, seed, p, self._hidden_act, self._output_act, self._flag(),
+                                            *self._params())
         return self.encode_decode(user_id, self.add_noise(x))
