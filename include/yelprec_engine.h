@@ -427,7 +427,11 @@ int yr_negative_mask(const float *positives, int64_t B, int64_t num_items, int n
  *   x is written.
  * yr_cdae_sparse_encode: z[B, H] from the lists, W_h [H, I], b_h [H], V [num_users, H], user [B];
  *   act 0 identity / 1 sigmoid (bias, user-node add and activation fused).
- * yr_cdae_sparse_dwh: dWh [H, I] += dz^T . lists (dWh zeroed by the caller; float atomics).
+ * yr_cdae_sparse_dwh: dWh [H, I] (all zero on entry) = dz^T . lists.  Two launches: the H-vector of every non-zero is added into
+ *   the transposed scratch_T [I, H] (contiguous float atomics), then the touched columns are moved into dWh and
+ *   cleared.  scratch_T: all zero on entry and on exit; claim int32[I]: any contents, never equal to a future
+ *   epoch (zero-fill once; pass a different non-zero `epoch` per call); touched int32[I], n_touched int32[1]:
+ *   scratch.
  * ------------------------------------------------------------------------- */
 int64_t yr_cdae_sparse_part_columns(int64_t I);
 int yr_cdae_compact_rows(const float *x, int64_t B, int64_t I, uint64_t seed, double p,
@@ -437,7 +441,9 @@ int yr_cdae_sparse_encode(const int32_t *cols, const float *vals, const int32_t 
                           int64_t B, int64_t I, int H, int64_t num_users, int act, float *z,
                           int32_t *err_flag, void *stream);
 int yr_cdae_sparse_dwh(const int32_t *cols, const float *vals, const int32_t *count,
-                       const float *dz, int64_t B, int64_t I, int H, float *dWh, void *stream);
+                       const float *dz, int64_t B, int64_t I, int H, float *dWh,
+                       float *scratch_T, int32_t *claim, int32_t epoch, int32_t *touched, int32_t *n_touched,
+                       void *stream);
 
 /* ---------------------------------------------------------------------------
  * Device-side BPR triplet stream   (reference train.py:76-77: DataLoader(MFDataset, shuffle=True);

@@ -72,7 +72,7 @@ SIGNATURES = {
     "yr_cdae_sparse_part_columns": [_i64],
     "yr_cdae_compact_rows": [_p, _i64, _i64, C.c_uint64, _d, _p, _p, _p, _p],
     "yr_cdae_sparse_encode": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _int, _i64, _int, _p, _p, _p],
-    "yr_cdae_sparse_dwh": [_p, _p, _p, _p, _i64, _i64, _int, _p, _p],
+    "yr_cdae_sparse_dwh": [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, C.c_int32, _p, _p, _p],
     "yr_triplet_sample": [_p, _p, _i64, _p, _p, _i64, _i64, C.c_uint64, C.c_uint64, _int, _i64, _i64,
                           _p, _p, _p, _p, _p],
 }

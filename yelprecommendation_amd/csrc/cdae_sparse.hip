@@ -152,26 +152,47 @@ __global__ __launch_bounds__(kBlock) void cdae_sparse_encode_kernel(
   }
 }
 
-__global__ __launch_bounds__(kBlock) void cdae_sparse_dwh_kernel(const int32_t* __restrict__ cols,
-                                                                 const float* __restrict__ vals,
-                                                                 const int32_t* __restrict__ count, int64_t cpp,
-                                                                 const float* __restrict__ dz, int64_t I, int H,
-                                                                 float* __restrict__ dWh) {
+// dW_h in two launches.  Adding dz[r, h] * val straight into dWh[h, col] (row pitch I) makes every lane of a
+// wave hit a different cache line (35 us of float atomics for ~5 k non-zeros at H = 128).  Instead:
+//   1  add the H-vector of every non-zero into a TRANSPOSED scratch T[col, 0..H) — 4 H contiguous bytes per
+//      non-zero, the shape the memory-side float atomics run at full rate for; the first workgroup to reach a
+//      column (atomic exchange on claim[col], stamped with the launch's epoch) puts the column on a list;
+//   2  one wave per listed column: dWh[h, col] = T[col, h] (plain strided stores; dWh is zero on entry), T[col, :] = 0.
+// T stays all-zero between steps; claim never needs clearing (the epoch changes every step).
+__global__ __launch_bounds__(kBlock) void cdae_sparse_dwh_accumulate_kernel(
+    const int32_t* __restrict__ cols, const float* __restrict__ vals, const int32_t* __restrict__ count, int64_t cpp,
+    const float* __restrict__ dz, int H, float* __restrict__ T, int32_t* __restrict__ claim, int32_t epoch,
+    int32_t* __restrict__ touched, int32_t* __restrict__ n_touched) {
   __shared__ int s_pre[kParts + 1];
   __shared__ int32_t s_col[kListCap];
   __shared__ float s_val[kListCap];
   const int64_t r = blockIdx.x;
-  for (int h0 = 0; h0 < H; h0 += kBlock) {
-    const int h = h0 + threadIdx.x;
-    const float g = h < H ? dz[r * H + h] : 0.0f;
-    float* wrow = dWh + (int64_t)min(h, H - 1) * I;
-    for (int skip = 0;; skip += kListCap) {
-      const int n = gather_row_list(cols, vals, count, cpp, r, skip, s_pre, s_col, s_val);
-      if (h < H)
-        for (int j = 0; j < n; ++j) atomicAdd(wrow + s_col[j], g * s_val[j]);
-      const bool more = skip + n < s_pre[kParts];
-      __syncthreads();
-      if (!more) break;
+  for (int skip = 0;; skip += kListCap) {
+    const int n = gather_row_list(cols, vals, count, cpp, r, skip, s_pre, s_col, s_val);
+    for (int j = threadIdx.x; j < n; j += kBlock)                 // claim the columns of this round
+      if (atomicExch(&claim[s_col[j]], epoch) != epoch) touched[atomicAdd(n_touched, 1)] = s_col[j];
+    for (int h = threadIdx.x; h < H; h += kBlock) {
+      const float g = dz[r * H + h];
+      for (int j = 0; j < n; ++j) atomicAdd(T + (int64_t)s_col[j] * H + h, g * s_val[j]);
+    }
+    const bool more = skip + n < s_pre[kParts];
+    __syncthreads();
+    if (!more) break;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void cdae_sparse_dwh_scatter_kernel(const int32_t* __restrict__ touched,
+                                                                         const int32_t* __restrict__ n_touched,
+                                                                         float* __restrict__ T, int64_t I, int H,
+                                                                         float* __restrict__ dWh) {
+  const int n = n_touched[0];
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+  for (int i = blockIdx.x * kWavesPerBlock + wave; i < n; i += gridDim.x * kWavesPerBlock) {   // a wave per column
+    const int64_t col = touched[i];
+    for (int h = lane; h < H; h += kWave) {
+      float* t = T + col * H + h;
+      dWh[(int64_t)h * I + col] = *t;                 // dWh is zero on entry: a store, not a strided read-modify-write
+      *t = 0.0f;
     }
   }
 }
@@ -209,11 +230,18 @@ extern "C" int yr_cdae_sparse_encode(const int32_t* cols, const float* vals, con
 }
 
 extern "C" int yr_cdae_sparse_dwh(const int32_t* cols, const float* vals, const int32_t* count, const float* dz,
-                                  int64_t B, int64_t I, int H, float* dWh, void* stream) {
+                                  int64_t B, int64_t I, int H, float* dWh, float* scratch_T, int32_t* claim,
+                                  int32_t epoch, int32_t* touched, int32_t* n_touched, void* stream) {
   if (B < 0 || I <= 0 || H <= 0) return YR_ERR_BADARG;
   if (B == 0) return 0;
-  if (!cols || !vals || !count || !dz || !dWh) return YR_ERR_BADARG;
-  hipLaunchKernelGGL(cdae_sparse_dwh_kernel, dim3((unsigned)B), dim3(kBlock), 0, (hipStream_t)stream, cols, vals, count,
-                     yr_cdae_sparse_part_columns(I), dz, I, H, dWh);
+  if (!cols || !vals || !count || !dz || !dWh || !scratch_T || !claim || !touched || !n_touched) return YR_ERR_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(n_touched, 0, sizeof(int32_t), s);
+  if (e != hipSuccess) return (int)e;
+  const int64_t cpp = yr_cdae_sparse_part_columns(I);
+  hipLaunchKernelGGL(cdae_sparse_dwh_accumulate_kernel, dim3((unsigned)B), dim3(kBlock), 0, s, cols, vals, count, cpp,
+                     dz, H, scratch_T, claim, epoch, touched, n_touched);
+  hipLaunchKernelGGL(cdae_sparse_dwh_scatter_kernel, dim3(2048), dim3(kBlock), 0, s, touched, n_touched, scratch_T, I,
+                     H, dWh);
   return launch_status();
 }

@@ -409,12 +409,26 @@ def cdae_sparse_encode(rows: "SparseRows", Wh, bh, V, user, act, err_flag=None):
     return z
 
 
+_dwh_scratch = {}
+
+
 def cdae_sparse_dwh(rows: "SparseRows", dz, dWh):
-    """dWh += dz^T . rows (dWh [H, I] zeroed by the caller)."""
+    """dWh (zero on entry) = dz^T . rows (dWh [H, I]); the transposed scratch and the column-claim words live per (device, I, H)."""
     lib = _lib.load()
+    H = dz.shape[1]
+    key = (dz.device, rows.I, H)
+    sc = _dwh_scratch.get(key)
+    if sc is None:
+        dev = dz.device
+        sc = _dwh_scratch[key] = [torch.zeros(rows.I, H, dtype=torch.float32, device=dev),
+                                  torch.zeros(rows.I, dtype=torch.int32, device=dev),
+                                  torch.empty(rows.I, dtype=torch.int32, device=dev),
+                                  torch.zeros(1, dtype=torch.int32, device=dev), 0]
+    sc[4] = sc[4] % 0x7ffffff0 + 1                       # a fresh non-zero epoch per call
     check(lib.yr_cdae_sparse_dwh(rows.cols.data_ptr(), rows.vals.data_ptr(), rows.count.data_ptr(),
-                                 _dev(dz, torch.float32, "dz"), rows.B, rows.I, dz.shape[1],
-                                 _dev(dWh, torch.float32, "dWh"), _stream()), "yr_cdae_sparse_dwh")
+                                 _dev(dz, torch.float32, "dz"), rows.B, rows.I, H, _dev(dWh, torch.float32, "dWh"),
+                                 sc[0].data_ptr(), sc[1].data_ptr(), sc[4], sc[2].data_ptr(), sc[3].data_ptr(),
+                                 _stream()), "yr_cdae_sparse_dwh")
     return dWh
 
 
