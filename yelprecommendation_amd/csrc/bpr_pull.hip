@@ -408,11 +408,12 @@ __device__ __forceinline__ void walk_stream(const OwnerArgs& a, const unsigned s
   if (!HEAVY) sums.book(cur_row >= 0, cur_row - row_base, cur, grp);
 }
 
-template <int D, bool USER, bool FUSE_ADAM, bool DET, bool ONEROW = false>
+template <int D, bool USER, bool FUSE_ADAM, bool DET, int RPWX = 0>
 __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(OwnerArgs a) {
   using G = PullGeom<D>;
   constexpr int LPR = G::LPR, GPW = G::GPW;
-  constexpr int RPW = ONEROW ? 1 : GPW;          // rows a wave owns
+  constexpr int RPW = RPWX ? RPWX : GPW;         // rows a wave owns (RPWX = 0: one per lane group)
+  static_assert(RPW <= GPW, "a wave finishes at most one row per lane group");
   constexpr int R = kWavesPerBlock * RPW;        // rows per bucket
   constexpr int CAP = USER ? kUserCap : kCap;    // records per chunk
   constexpr int PT = CAP / kBlock;
@@ -431,8 +432,8 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
   __shared__ int s_scan[kWavesPerBlock];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   const int grp = lane / LPR, l = lane % LPR;
-  const int row_l = wave * RPW + (ONEROW ? 0 : grp);   // the row this lane group finishes (ONEROW: group 0 only)
-  const bool finisher = !ONEROW || grp == 0;
+  const bool finisher = grp < RPW;                // lane groups that finish a row (all of them unless RPW < GPW)
+  const int row_l = wave * RPW + (finisher ? grp : 0);
   float loss = 0.0f;
 #ifdef YR_STAMPS
   bool first_bucket = true;
@@ -699,7 +700,7 @@ inline PullPlan make_plan(int64_t B, int64_t nU, int64_t nI, int D, bool upper_b
   p.narrow_users = (nU + R - 1) / R < kNarrowBelow && R > kNarrowRows;
   p.shiftU = p.narrow_users ? kNarrowShift : p.shiftI;
   p.nbU = (int)((nU + (1 << p.shiftU) - 1) >> p.shiftU);
-  p.nbI = (int)((nI + R - 1) / R);
+  p.nbI = (int)((nI + (1 << p.shiftI) - 1) >> p.shiftI);
   p.pt = tile_pt(B);
   p.tile = kPartThreads * p.pt;
   p.T = (int)((B + p.tile - 1) / p.tile);
@@ -809,7 +810,6 @@ static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU
                            float* gradI_out, int64_t B, int64_t nU, int64_t nI, float inv_batch, const AdamC& adam,
                            int deterministic, void* workspace, float* loss_partials, float* loss_out,
                            double* loss_accum, int phases, int64_t item_begin, int64_t item_end, hipStream_t s) {
-  using G = PullGeom<D>;
   const PullPlan p = make_plan(B, nU, nI, D, false);
   char* w = static_cast<char*>(workspace);
   const bool want_loss = loss_out || loss_accum;
@@ -823,9 +823,9 @@ static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU
     ua.heavy_t = kHeavyRow; ua.inv_batch = inv_batch; ua.adam = adam;
     const int gu = p.nbU < YR_LOSS_PARTIALS ? p.nbU : YR_LOSS_PARTIALS;   // one loss-partial slot per workgroup
     if (p.narrow_users && deterministic)
-      hipLaunchKernelGGL((owner_pass_kernel<D, true, true, true, true>), dim3(gu), dim3(kBlock), 0, s, ua);
+      hipLaunchKernelGGL((owner_pass_kernel<D, true, true, true, 1>), dim3(gu), dim3(kBlock), 0, s, ua);
     else if (p.narrow_users)
-      hipLaunchKernelGGL((owner_pass_kernel<D, true, true, false, true>), dim3(gu), dim3(kBlock), 0, s, ua);
+      hipLaunchKernelGGL((owner_pass_kernel<D, true, true, false, 1>), dim3(gu), dim3(kBlock), 0, s, ua);
     else if (deterministic)
       hipLaunchKernelGGL((owner_pass_kernel<D, true, true, true>), dim3(gu), dim3(kBlock), 0, s, ua);
     else
@@ -839,8 +839,8 @@ static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU
     ia.loss_partials = loss_partials; ia.loss_out = loss_out; ia.loss_accum = loss_accum;
     ia.finalize = want_loss ? 1 : 0;
     ia.nb = p.nbI; ia.T = p.T; ia.tile_stride = 2 * p.tile; ia.rows = (int)nI;
-    ia.bucket_begin = (int)(item_begin / G::R);
-    ia.bucket_end = (int)((item_end + G::R - 1) / G::R);
+    ia.bucket_begin = (int)(item_begin >> p.shiftI);
+    ia.bucket_end = (int)((item_end + (1 << p.shiftI) - 1) >> p.shiftI);
     ia.heavy_t = kHeavyRow; ia.inv_batch = inv_batch; ia.adam = adam;
     int gi = ia.bucket_end - ia.bucket_begin;
     if (gi > kMaxOwnerGrid) gi = kMaxOwnerGrid;
