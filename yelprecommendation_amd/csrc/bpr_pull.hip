@@ -49,7 +49,10 @@
 namespace yr {
 
 constexpr int kPartThreads = 1024;              // partition workgroup
-constexpr int kCap = 1024;                      // records an owner workgroup sorts per chunk (item side)
+#ifndef YR_ITEM_CAP
+#define YR_ITEM_CAP 1024
+#endif
+constexpr int kCap = YR_ITEM_CAP;                      // records an owner workgroup sorts per chunk (item side)
 constexpr int kUserCap = 768;                   // user side (12 B of LDS per record instead of 8)
 constexpr int kTileGroup = 256;                 // tiles whose segment descriptors an owner holds at once
 constexpr int kOccShift = 26;                   // occ.x = user | local item row << 26
