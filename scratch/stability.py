@@ -1,27 +1,31 @@
-"""Stability soak: many pull-form steps on changing batches; two instances fed the same stream must stay
-within float rounding of each other (a race or a lost contribution shows up as a jump), no flags, no NaN."""
+"""Stability soak: many steps on changing batches (sizes from 1 to 2^20, popularity-skewed items).  Three
+instances fed the same stream — auto (atomic below 24,576 triplets, pull above), pull only, pull deterministic
+with the multi-GPU shape of the item update — must stay within float rounding of each other (a race or a lost
+contribution shows up as a jump), no flags, no NaN."""
 import sys, time, torch
 sys.path.insert(0, '.')
 from yelprecommendation_amd.bpr_step import BPRMFStep
 dev = torch.device('cuda'); g = torch.Generator(device=dev).manual_seed(0)
 nu, ni, d = 31668, 38048, 64
 U0 = torch.randn(nu, d, device=dev, generator=g) * 0.05; I0 = torch.randn(ni, d, device=dev, generator=g) * 0.05
-a = BPRMFStep(U0.clone(), I0.clone(), lr=1e-3, impl="pull")
-b = BPRMFStep(U0.clone(), I0.clone(), lr=1e-3, impl="pull", split_item_update=True, item_chunks=3)
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+a = BPRMFStep(U0.clone(), I0.clone(), lr=1e-3, impl="auto")
+b = BPRMFStep(U0.clone(), I0.clone(), lr=1e-3, impl="pull")
+c = BPRMFStep(U0.clone(), I0.clone(), lr=1e-3, impl="pull", deterministic=True, split_item_update=True, item_chunks=3)
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 t0 = time.time(); worst = 0.0
+sizes = [1, 7, 33, 1000, 4097, 20000, 24576, 40000, 65536, 100001, 262144, 400000, 524288, 920629, 1 << 20]
 for s in range(steps):
-    B = int(torch.randint(120000, 1 << 20, (1,)).item())
+    B = sizes[int(torch.randint(0, len(sizes), (1,)).item())] if s % 3 else int(torch.randint(1, 300000, (1,)).item())
     u = torch.randint(0, nu, (B,), device=dev, generator=g)
-    # popularity-skewed items: a few very heavy rows
-    p = (torch.rand(B, device=dev, generator=g) ** 3 * ni).long().clamp_(max=ni - 1)
+    p = (torch.rand(B, device=dev, generator=g) ** 2 * ni).long().clamp_(max=ni - 1)     # a few heavy rows
     n = torch.randint(0, ni, (B,), device=dev, generator=g)
-    a.step(u, p, n); b.step(u, p, n)
-    if s % 250 == 249:
-        dU = (a.U - b.U).abs().max().item(); dI = (a.I - b.I).abs().max().item()
+    a.step(u, p, n); b.step(u, p, n); c.step(u, p, n)
+    if s % 200 == 199:
+        dU = max((a.U - b.U).abs().max().item(), (c.U - b.U).abs().max().item())
+        dI = max((a.I - b.I).abs().max().item(), (c.I - b.I).abs().max().item())
         worst = max(worst, dU, dI)
-        assert torch.isfinite(a.U).all() and torch.isfinite(a.I).all()
+        assert torch.isfinite(a.U).all() and torch.isfinite(a.I).all() and torch.isfinite(c.U).all()
         assert dU < 5e-4 and dI < 5e-4, (s, dU, dI)
-        a.check(); b.check()
-        print(f"step {s+1}: max |dU| {dU:.2e} |dI| {dI:.2e}  loss {a.epoch_loss():.4f} / {b.epoch_loss():.4f}  ({time.time()-t0:.0f} s)", flush=True)
+        a.check(); b.check(); c.check()
+        print(f"step {s+1}: max |dU| {dU:.2e} |dI| {dI:.2e}  loss {a.epoch_loss():.4f} / {b.epoch_loss():.4f} / {c.epoch_loss():.4f}  ({time.time()-t0:.0f} s)", flush=True)
 print("stable over", steps, "steps; worst divergence", worst)
