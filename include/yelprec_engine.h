@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 19
+#define YR_ENGINE_VERSION 20
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -50,6 +50,11 @@ extern "C" {
 /* Number of float32 partial sums a loss-producing kernel writes (one per workgroup
  * slot, unused slots written as 0).  Callers size `loss_partials` with this.      */
 #define YR_LOSS_PARTIALS 2048
+/* A count that many workgroups add to (yr_cdae_decode_loss) is kept as YR_COUNT_SLOTS partial counts, one per
+ * 128-byte line of a YR_COUNT_WORDS-word int32 buffer (word s * YR_COUNT_WORDS / YR_COUNT_SLOTS); its readers
+ * (yr_gemm_f32_ex alpha_count, yr_cdae_hidden_bwd) add the slots up. */
+#define YR_COUNT_SLOTS 64
+#define YR_COUNT_WORDS 2048
 
 /* Load check: returns YR_ENGINE_VERSION. */
 int yr_engine_version(void);
@@ -274,6 +279,37 @@ int yr_ngcf_dense_bwd_weight(const float *dEout, const float *Eout, const float 
 int yr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
                 const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
                 const float *bias, int act, int accumulate, int split_k, void *stream);
+/* yr_gemm_f32_ex: yr_gemm_f32 with two extras (16-byte aligned operands, lda / ldb multiples of 4 only):
+ *   alpha_count  device int32[YR_COUNT_WORDS] (a spread count, see YR_COUNT_SLOTS): the product is scaled by
+ *                1 / count (by 0 when the count is 0) — the 1 / (number of loss positions) of a mean loss that
+ *                only the device knows;
+ *   rowsum       rowsum[m] = alpha * sum_k op(A)(m,k), from the operand values the MFMAs read anyway (the
+ *                bias gradient beside dW = G^T z; split_k must be 1).
+ * The three entry points below are the fused pieces of one CDAE training step (cdae_trainer.py:36-54:
+ * forward, NS-BCE / BCE, backward), driven by yelprecommendation_amd/cdae_step.py:
+ * yr_cdae_decode_loss: y = act(z W_o^T + b_o) on the matrix cores with the loss in the epilogue:
+ *   G[b,i] = (y - t) / max((1 - y) y, 1e-12) * act'(y) on the selected positions (target + negative_mask != 0;
+ *   every position when negative_mask is NULL), else 0 — the gradient w.r.t. the decoder's pre-activation
+ *   WITHOUT its 1 / count factor; partial_loss[yr_cdae_decode_loss_partials(B, I)] = per-workgroup sums of the
+ *   clamped BCE terms; count (int32[YR_COUNT_WORDS], all zero on entry) += number of selected positions,
+ *   spread over its slots.  pred (may be NULL)
+ *   receives y.  z / Wo 16-byte aligned, H a multiple of 4; ldg >= I = leading dimension of G and pred (a
+ *   multiple of 4 lets the gradient products that read G take the tiled kernel).
+ * yr_cdae_hidden_bwd: dz <- dz * act'(z) in place, dbh = column sums, dV[user[b],:] += dz[b,:] with
+ *   touched_users[user[b]] = 1 (may be NULL); with n_partials > 0 also the step's loss: stats[0] = (sum of
+ *   partial_loss in fixed order) / count, stats[1] = count, *loss_accum += stats[0] (may be NULL). */
+int yr_gemm_f32_ex(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                   const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                   const float *bias, int act, int accumulate, int split_k,
+                   const int32_t *alpha_count, float *rowsum, void *stream);
+int64_t yr_cdae_decode_loss_partials(int64_t B, int64_t I);
+int yr_cdae_decode_loss(const float *z, const float *Wo, const float *bo, const float *target,
+                        const float *negative_mask, int64_t B, int64_t I, int H, int act, float *G,
+                        int64_t ldg, float *pred, float *partial_loss, int32_t *count, void *stream);
+int yr_cdae_hidden_bwd(float *dz, const float *z, int act, const int64_t *user, int64_t B, int H,
+                       int64_t num_users, float *dV, uint8_t *touched_users, float *dbh,
+                       const float *partial_loss, int64_t n_partials, const int32_t *count,
+                       float *stats, double *loss_accum, void *stream);
 int yr_cdae_hidden_init(float *zpre, const float *bias, const float *V, const int64_t *user,
                         int64_t B, int H, int64_t num_users, int32_t *err_flag, void *stream);
 int yr_dropout(const float *x, const float *rnd, double p, int64_t n, float *out, void *stream);
@@ -396,6 +432,15 @@ int yr_adam_dense_multi(float *const *p, float *const *g, float *const *m, float
                         const int64_t *n, int count, double lr, double step_size, double bc2_sqrt,
                         double beta1, double beta2, double eps, double weight_decay, int mode,
                         int zero_grad, void *stream);
+/* yr_adam_dense_flat: up to YR_ADAM_MULTI_MAX tensors of ANY size in one launch at 16 bytes per lane
+ * (every buffer 16-byte aligned).  touched[k] (HOST array of device pointers,
+ * entries may be NULL): one byte per row of row_width[k] floats (row_width / 4 a power of two <= 64) — the
+ * gradient of a row is read, cleared and unmarked only where the mark is set (every row is still updated, with
+ * grad = 0 elsewhere).  clear[k] != 0: the gradient is cleared after it is read. */
+int yr_adam_dense_flat(float *const *p, float *const *g, float *const *m, float *const *v,
+                       const int64_t *n, uint8_t *const *touched, const int *row_width, const int *clear,
+                       int count, double lr, double step_size, double bc2_sqrt, double beta1,
+                       double beta2, double eps, double weight_decay, int mode, void *stream);
 int yr_sgd_dense(float *p, float *g, int64_t n, double lr, double weight_decay,
                  int zero_grad, void *stream);
 

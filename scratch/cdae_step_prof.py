@@ -1,23 +1,48 @@
-"""Full-size CDAE step (I = 38,048, H = 128, batch 256): wall time per step; run under rocprofv3 for the kernel split."""
-import sys, time, torch
-sys.path.insert(0, '.')
+"""CDAE full-size step: fused (cdae_step.py) vs autograd route, ms per step; optional per-launch profile via rocprofv3."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from yelprecommendation_amd.cdae_step import CDAEStep
 from yelprecommendation_amd.loss import NSBCELoss
 from yelprecommendation_amd.models.cdae import CDAE
 from yelprecommendation_amd.optim import Adam
 from yelprecommendation_amd.utils import make_config
-dev = torch.device('cuda:0'); NU, NI = 31668, 38048
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 256; steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-model = CDAE(make_config("CDAE", hidden_size=128, device="cuda", model_dir="/tmp/yr_bench", lr=1e-4), NI, NU)
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "both"
+NU, NI, B, H = 31668, 38048, 256, 128
+dev = torch.device("cuda")
+model = CDAE(make_config("CDAE", hidden_size=H, device="cuda", model_dir="/tmp/yr_bench", lr=1e-4), NI, NU)
 opt, lossf = Adam(model.parameters(), lr=1e-4), NSBCELoss()
 users = torch.randperm(NU, device=dev)[:B]
-x = (torch.rand(B, NI, device=dev) < 0.0013).float()
-neg = (torch.rand(B, NI, device=dev) < 0.0065).float() * (1 - x)
+x = (torch.rand(B, NI, device=dev) < 0.0008).float()
+neg = (torch.rand(B, NI, device=dev) < 0.004).float() * (1 - x)
 model.train()
-def step():
+
+
+def timed(fn, n=60, w=10):
+    for _ in range(w):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def auto():
     pred = model(users, x)
     opt.zero_grad(); lossf(pred, x, neg).backward(); opt.step()
-for _ in range(10): step()
-torch.cuda.synchronize(); t = time.perf_counter()
-for _ in range(steps): step()
-torch.cuda.synchronize(); dt = (time.perf_counter() - t) / steps
-print(f"CDAE step B={B}: {dt*1e3:.3f} ms", flush=True)
+
+
+if mode in ("both", "auto"):
+    print("autograd route  %.4f ms" % timed(auto), flush=True)
+if mode in ("both", "fused"):
+    step = CDAEStep(model, opt)
+    k = [0]
+
+    def fused():
+        k[0] += 1
+        step.step(users, x, neg, seed=k[0], p=model.corruption_level)
+    print("fused step      %.4f ms" % timed(fused), flush=True)
+    print("loss", float(step.last_loss()))

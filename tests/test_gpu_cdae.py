@@ -165,9 +165,14 @@ def test_seeded_dropout_is_a_fair_reproducible_mask(device):
     assert torch.equal(m1, m2) and not torch.equal(m1, m3)
 
 
-def test_trainer_run_matches_reference(g, tmp_path, device):
+@pytest.mark.parametrize("fused_step", [True, False])
+def test_trainer_run_matches_reference(g, tmp_path, device, fused_step):
+    """The reference's recorded run, once through the fused step (cdae_step.py, the default) and once launch by
+    launch through autograd (model node + loss module + optimizer.step)."""
     from yelprecommendation_amd.trainers import CDAETrainer
-    t = CDAETrainer(_cfg(g, tmp_path, negative_sampling=True), int(g["num_items"]), int(g["num_users"]))
+    t = CDAETrainer(_cfg(g, tmp_path, negative_sampling=True, fused_step=fused_step), int(g["num_items"]),
+                    int(g["num_users"]))
+    assert (t._fused_step() is not None) == fused_step
     _load(t.model, g, "init")
     X = g["train_input"].astype(np.float32)
     VM = g["valid_mask"].astype(np.float32)
@@ -359,3 +364,131 @@ def test_user_indexed_item_lists_equal_mask_derived_lists(device, tmp_path, g):
     i2 = torch.cat([idx[ptr[r]:ptr[r + 1]] for r in rows.tolist()])
     assert torch.equal(got, engine.topk_masked(scores, p2, i2, 10))
     torch.testing.assert_close(engine.rank_metrics(got, ptr, idx, pos_rows=rows), engine.rank_metrics(got, p2, i2), rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("tA", [False, True])
+@pytest.mark.parametrize("tB", [False, True])
+@pytest.mark.parametrize("M,N,K,split", [(300, 128, 136, 1), (2048, 8200, 72, 1), (256, 128, 5000, 8)])
+def test_gemm_ex_count_scale_and_row_sums(device, tA, tB, M, N, K, split):
+    """yr_gemm_f32_ex: the product scaled by 1 / (a count that lives on the device) and, without a K split,
+    the row sums of op(A) from the same pass; a zero count scales by 0 (the empty-loss convention)."""
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(5 * M + N + K + 2 * tA + tB)
+    A = rs.standard_normal((K, M) if tA else (M, K)).astype(np.float32)
+    B = rs.standard_normal((N, K) if tB else (K, N)).astype(np.float32)
+    opA = (A.T if tA else A).astype(np.float64)
+    want = opA @ (B.T if tB else B).astype(np.float64)
+    dA, dB = torch.from_numpy(A).to(device), torch.from_numpy(B).to(device)
+    for c in (7, 0):
+        count = engine.spread_count(c, device)
+        scale = 1.0 / c if c else 0.0
+        rowsum = torch.full((M,), -1.0, dtype=torch.float32, device=device) if split == 1 else None
+        out = torch.zeros(M, N, dtype=torch.float32, device=device)
+        engine.gemm_f32(dA, dB, transA=tA, transB=tB, out=out, accumulate=split > 1, split_k=split,
+                        alpha_count=count, rowsum=rowsum)
+        np.testing.assert_allclose(out.cpu().numpy(), want * scale, rtol=1e-4, atol=2e-5 * np.sqrt(K) * 4)
+        if rowsum is not None:
+            np.testing.assert_allclose(rowsum.cpu().numpy(), opA.sum(1) * scale, rtol=1e-4, atol=1e-4)
+    with pytest.raises(engine.EngineError):                       # row sums need the whole of K in one pass
+        engine.gemm_f32(dA, dB, transA=tA, transB=tB, out=out, accumulate=True, split_k=4,
+                        alpha_count=count, rowsum=torch.zeros(M, device=device))
+
+
+def test_adam_flat_equals_adam_dense(device):
+    """One launch over five tensors of any size == five yr_adam_dense launches, bit for bit; marked rows: only
+    their gradient is read (stale values elsewhere are ignored), and it is cleared with the mark."""
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(8)
+    shapes = [(128, 1503), (128,), (300, 128), (1503, 128), (1503,), (7,), (3, 5)]
+    mk = lambda s, scale=1.0: torch.from_numpy((rs.standard_normal(s) * scale).astype(np.float32)).to(device)
+    for decoupled, wd in ((False, 0.0), (False, 0.01), (True, 0.01)):
+        P, G = [mk(s) for s in shapes], [mk(s, 0.1) for s in shapes]
+        M, V = [mk(s, 0.01) for s in shapes], [mk(s, 0.01).abs() for s in shapes]
+        marks = torch.zeros(300, dtype=torch.uint8, device=device)
+        hit = torch.from_numpy(rs.choice(300, 40, replace=False)).to(device)
+        marks[hit] = 1
+        Gd = [g.clone() for g in G]
+        Gd[2] = torch.zeros_like(G[2]); Gd[2][hit] = G[2][hit]          # what the marked form stands for
+        want = [(p.clone(), m.clone(), v.clone()) for p, m, v in zip(P, M, V)]
+        for (p, m, v), g in zip(want, Gd):
+            flat = [t.reshape(-1) for t in (p, g.clone(), m, v)]
+            if flat[0].numel() % 4 == 0:
+                engine.adam_dense(*flat, 3, 1e-2, 0.9, 0.999, 1e-8, wd, decoupled=decoupled)
+            else:
+                engine.adam_dense_multi([tuple(flat)], 3, 1e-2, 0.9, 0.999, 1e-8, wd, decoupled=decoupled)
+        tensors = [(p, g, m, v, marks if k == 2 else None, k == 0) for k, (p, g, m, v) in enumerate(zip(P, G, M, V))]
+        engine.adam_dense_flat(tensors, 3, 1e-2, 0.9, 0.999, 1e-8, wd, decoupled=decoupled)
+        for k, ((p, m, v), gp, gm, gv) in enumerate(zip(want, P, M, V)):
+            assert torch.equal(p, gp) and torch.equal(m, gm) and torch.equal(v, gv), k
+        assert int(marks.sum()) == 0 and float(G[2][hit].abs().sum()) == 0.0        # consumed: cleared + unmarked
+        assert float(G[0].abs().sum()) == 0.0 and float(G[3].abs().sum()) > 0.0     # clear flag / left alone
+
+
+@pytest.mark.parametrize("ni,negative_sampling", [(1501, True), (1504, True), (1503, False)])
+def test_fused_step_equals_autograd_route(device, tmp_path, ni, negative_sampling):
+    """cdae_step.CDAEStep (decoder with the loss in its epilogue, count-scaled gradient products, one Adam launch)
+    against the autograd route (model + loss module + optimizer.step) over four steps from the same init, with
+    the same dropout seeds: losses, all parameters, all Adam moments.  Ragged catalogue widths, duplicate users,
+    an all-zero row; NS-BCE and plain BCE; then both against the NumPy oracle for the first step."""
+    from yelprecommendation_amd.cdae_step import CDAEStep
+    from yelprecommendation_amd.loss import BCELoss, NSBCELoss
+    from yelprecommendation_amd.models.cdae import CDAE
+    from yelprecommendation_amd.optim import Adam
+    from yelprecommendation_amd.utils import make_config
+    rs = np.random.RandomState(ni)
+    nu, H, B, steps = 90, 128, 40, 4
+    t = lambda a: torch.from_numpy(a).to(device)
+    batches = []
+    for _ in range(steps):
+        u = rs.randint(0, nu, B).astype(np.int64); u[7] = u[2]
+        x = (rs.rand(B, ni) < 0.02).astype(np.float32); x[3] = 0.0
+        neg = ((rs.rand(B, ni) < 0.1) * (1 - x)).astype(np.float32)
+        batches.append((u, x, neg, int(rs.randint(1, 1 << 40))))
+    out = {}
+    for fused in (False, True):
+        torch.manual_seed(3)
+        model = CDAE(make_config("CDAE", hidden_size=H, device="cuda", model_dir=str(tmp_path), lr=1e-3), ni, nu)
+        model.train()
+        opt = Adam(model.parameters(), lr=1e-3)
+        losses = []
+        if fused:
+            step = CDAEStep(model, opt, negative_sampling)
+            for u, x, neg, seed in batches:
+                step.step(t(u), t(x), t(neg) if negative_sampling else None, seed=seed, p=model.corruption_level)
+                losses.append(float(step.last_loss()))
+            assert abs(step.epoch_loss() - sum(losses)) < 1e-5 and float(step.dV.abs().sum()) == 0.0 \
+                and float(step.dWh.abs().sum()) == 0.0
+            step.check()
+        else:
+            lossf = NSBCELoss() if negative_sampling else BCELoss()
+            for u, x, neg, seed in batches:
+                xin = engine_dropout(t(x), seed, model.corruption_level)
+                pred = model.encode_decode(t(u), xin)
+                loss = lossf(pred, t(x), t(neg)) if negative_sampling else lossf(pred, t(x))
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(float(loss.detach()))
+        out[fused] = (losses, [p.detach().clone() for p in model.parameters()],
+                      [opt.state[p]["exp_avg"].clone() for p in model.parameters()],
+                      [opt.state[p]["exp_avg_sq"].clone() for p in model.parameters()])
+        assert all(opt.state[p]["step"] == steps for p in model.parameters())
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=2e-6)
+    for k in (1, 2, 3):
+        for a, b in zip(out[True][k], out[False][k]):
+            torch.testing.assert_close(a, b, rtol=2e-4, atol=1e-7 + 2e-5 * float(b.abs().max()))
+    # and the first step against the oracle (recomputed from the same init)
+    torch.manual_seed(3)
+    model = CDAE(make_config("CDAE", hidden_size=H, device="cuda", model_dir=str(tmp_path), lr=1e-3), ni, nu)
+    ref = ocdae.CDAEState([p.detach().cpu().numpy().copy() for p in model.parameters()], lr=1e-3)
+    u, x, neg, seed = batches[0]
+    xin = engine_dropout(t(x), seed, model.corruption_level).cpu().numpy()
+    want = float(ref.train_step(u, xin, x, neg if negative_sampling else np.ones_like(x)))
+    step = CDAEStep(model, Adam(model.parameters(), lr=1e-3), negative_sampling)
+    step.step(t(u), t(x), t(neg) if negative_sampling else None, seed=seed, p=model.corruption_level)
+    np.testing.assert_allclose(float(step.last_loss()), want, rtol=1e-5)
+    for p, r in zip(model.parameters(), ref.params):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), r, rtol=1e-3, atol=2e-6)
+
+
+def engine_dropout(x, seed, p):
+    from yelprecommendation_amd import engine
+    return engine.dropout_seeded(x, seed, p) if p > 0 else x

@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
-ENGINE_VERSION = 19
+ENGINE_VERSION = 20
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -43,6 +43,10 @@ SIGNATURES = {
     "yr_ngcf_dense_bwd_data": [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p],
     "yr_ngcf_dense_bwd_weight": [_p, _p, _p, _p, _i64, _int, _p, _p, _p],
     "yr_gemm_f32": [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _int, _int, _int, _p],
+    "yr_gemm_f32_ex": [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _int, _int, _int, _p, _p, _p],
+    "yr_cdae_decode_loss_partials": [_i64, _i64],
+    "yr_cdae_decode_loss": [_p, _p, _p, _p, _p, _i64, _i64, _int, _int, _p, _i64, _p, _p, _p, _p],
+    "yr_cdae_hidden_bwd": [_p, _p, _int, _p, _i64, _int, _i64, _p, _p, _p, _p, _i64, _p, _p, _p, _p],
     "yr_cdae_hidden_init": [_p, _p, _p, _p, _i64, _int, _i64, _p, _p],
     "yr_dropout": [_p, _p, _d, _i64, _p, _p],
     "yr_sigmoid": [_p, _i64, _p],
@@ -66,6 +70,7 @@ SIGNATURES = {
     "yr_bpr_loss_bwd": [_p, _p, _p, _f, _i64, _p, _p, _p],
     "yr_adam_dense": [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _d, _d, _int, _int, _p],
     "yr_adam_dense_multi": [_p, _p, _p, _p, _p, _int, _d, _d, _d, _d, _d, _d, _d, _int, _int, _p],
+    "yr_adam_dense_flat": [_p, _p, _p, _p, _p, _p, _p, _p, _int, _d, _d, _d, _d, _d, _d, _d, _int, _p],
     "yr_csr_rows_to_dense": [_p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p],
     "yr_negative_mask": [_p, _i64, _i64, _int, C.c_uint64, _p, _p, _p],
     "yr_sgd_dense": [_p, _p, _i64, _d, _d, _int, _p],
@@ -112,6 +117,7 @@ def load():
                       "yr_bpr_mf_pull_workspace_bytes": C.c_int64,
                       "yr_rank_metrics_workspace_bytes": C.c_int64,
                       "yr_cdae_sparse_part_columns": C.c_int64,
+                      "yr_cdae_decode_loss_partials": C.c_int64,
                       "yr_mf_eval_topk_workspace_bytes": C.c_int64}.get(name, C.c_int)
     v = lib.yr_engine_version()
     if v != ENGINE_VERSION:

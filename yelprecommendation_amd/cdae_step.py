@@ -1,0 +1,132 @@
+"""One CDAE training step as a fixed sequence of HIP launches (the CDAE counterpart of bpr_step.py).
+
+What the reference does per batch (trainers/cdae_trainer.py:36-54) —
+``pred = model(user_id, input_mask); optimizer.zero_grad(); loss(pred, input_mask, negative_mask).backward();
+optimizer.step()`` — with models/cdae.py:46-52 and loss.py:12-16 underneath, computed without autograd and
+without materialising ``pred`` or the loss gradient w.r.t. it:
+
+    1  non-zeros of dropout_p(x) as per-row lists                                yr_cdae_compact_rows
+    2  z = act_h(W_h . rows + b_h + V[u])                                        yr_cdae_sparse_encode
+    3  (clear dz and the position counter: one memset)
+    4  y = act_o(z W_o^T + b_o) on the matrix cores; epilogue: BCE terms of the selected positions ->
+       per-workgroup loss partials + their count, G = d loss / d pre-activation without 1 / count
+                                                                                 yr_cdae_decode_loss
+    5  dW_o = (G^T z) / count, db_o = its row sums of G^T / count                yr_gemm_f32_ex (rowsum)
+    6  dz = (G W_o) / count  (K split over the catalogue, atomics)               yr_gemm_f32_ex
+    7  dz *= act_h'(z); db_h = column sums; dV[u] += dz; loss of the step        yr_cdae_hidden_bwd
+    8  dW_h = dz^T . rows                                                        yr_cdae_sparse_dwh
+    9  Adam / AdamW on all five parameters                                       yr_adam_dense_flat
+
+Eleven launches (8 is a memset and two kernels) against ~26 through autograd, and 5 passes over [B, I]
+data instead of 11.  The gradient buffers belong to the step: dW_h and dV stay all-zero between steps (the
+Adam launch clears what it read — for dV only the rows the batch touched), dW_o / db_o / db_h are
+overwritten whole.  Results equal the autograd route (models/cdae.py + loss.py + optim.py) up to float
+rounding: the 1 / count factor is applied to the products instead of to G.
+"""
+import torch
+
+from . import engine
+
+
+class CDAEStep:
+    def __init__(self, model, optimizer, negative_sampling=True):
+        from . import optim
+        if not isinstance(optimizer, optim.Adam):
+            raise NotImplementedError("CDAEStep: optimizer adam or adamw")
+        self.model, self.optimizer, self.negative_sampling = model, optimizer, bool(negative_sampling)
+        self.params = [model.hidden_layer.weight, model.hidden_layer.bias, model.user_nodes.weight,
+                       model.output_layer.weight, model.output_layer.bias]
+        if model.hidden_size % 4:
+            raise NotImplementedError("CDAEStep: hidden size must be a multiple of 4")
+        dev = self.params[0].device
+        Wh, bh, V, Wo, bo = (p.data for p in self.params)
+        f32 = torch.float32
+        self.dWh, self.dV = torch.zeros_like(Wh), torch.zeros_like(V)          # all-zero between steps
+        self.dbh, self.dWo, self.dbo = torch.empty_like(bh), torch.empty_like(Wo), torch.empty_like(bo)
+        self.touched_users = torch.zeros(V.shape[0], dtype=torch.uint8, device=dev)
+        self.stats = torch.zeros(2, dtype=f32, device=dev)
+        self.loss_accum = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.flag = engine.new_error_flag(dev)
+        self._batch = None
+        for p in self.params:                                                   # the optimizer's own Adam state
+            st = optimizer.state[p]
+            if not st:
+                st["step"] = 0
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+
+    def bound_to(self, model, optimizer):
+        """Still bound to these parameter / state tensors (they are replaced by load_state_dict)?"""
+        if model is not self.model or optimizer is not self.optimizer:
+            return False
+        ps = [model.hidden_layer.weight, model.hidden_layer.bias, model.user_nodes.weight,
+              model.output_layer.weight, model.output_layer.bias]
+        return all(a is b for a, b in zip(ps, self.params)) and all("exp_avg" in optimizer.state[p] for p in ps)
+
+    def _buffers(self, B):
+        if self._batch != B:
+            Wh = self.params[0]
+            H, I = Wh.shape
+            dev, f32 = Wh.device, torch.float32
+            self.z = torch.empty(B, H, dtype=f32, device=dev)
+            ldg = (I + 3) // 4 * 4                                                # 16-byte rows: the gradient products
+            self.G = torch.empty(B, ldg, dtype=f32, device=dev)[:, :I]           # that read G take the tiled kernel
+            blob = torch.zeros(B * H + engine.COUNT_WORDS, dtype=f32, device=dev)   # dz and the (spread) position
+            self._blob = blob                                                   # counter: one memset clears both
+            self.dz = blob[:B * H].view(B, H)
+            self.count = blob[B * H:].view(torch.int32)
+            self.n_partials = engine.cdae_decode_loss_partials(B, I)
+            self.partials = torch.empty(self.n_partials, dtype=f32, device=dev)
+            self.row_count = torch.empty(B * engine.SPARSE_PARTS, dtype=torch.int32, device=dev)
+            self._batch = B
+
+    @torch.no_grad()
+    def step(self, user_id, x, negative_mask=None, seed=0, p=0.0, x_in=None):
+        """One training step on the batch.  ``x``: the uncorrupted [B, I] input (the loss target);
+        ``negative_mask``: [B, I] or None (plain BCE over every position).  The encoder input is
+        dropout_p(x) with the Philox mask of ``seed`` — or ``x_in`` when given (an already corrupted input)."""
+        model = self.model
+        Wh, bh, V, Wo, bo = (q.data for q in self.params)
+        B = x.shape[0]
+        if B == 0:
+            return
+        self._buffers(B)
+        user_id = user_id.contiguous()
+        x = x.contiguous()
+        rows = engine.SparseRows(x if x_in is None else x_in.contiguous(), seed if x_in is None else 0,
+                                 p if x_in is None else 0.0, count=self.row_count)
+        engine.cdae_sparse_encode(rows, Wh, bh, V, user_id, model._hidden_act, err_flag=self.flag, out=self.z)
+        self._blob.zero_()
+        neg = None if negative_mask is None else negative_mask.contiguous()
+        engine.cdae_decode_loss(self.z, Wo, bo, x, neg, model._output_act, self.G, self.partials, self.count)
+        engine.gemm_f32(self.G, self.z, transA=True, out=self.dWo, alpha_count=self.count, rowsum=self.dbo)
+        engine.gemm_f32(self.G, Wo, out=self.dz, accumulate=True, split_k=max(1, min(256, Wo.shape[0] // 256)),
+                        alpha_count=self.count)
+        engine.cdae_hidden_bwd(self.dz, self.z, model._hidden_act, user_id, self.dV, self.touched_users, self.dbh,
+                               self.partials, self.n_partials, self.count, self.stats, self.loss_accum)
+        engine.cdae_sparse_dwh(rows, self.dz, self.dWh)
+        group = self.optimizer.param_groups[0]
+        st = [self.optimizer.state[q] for q in self.params]
+        t = int(st[0]["step"]) + 1
+        grads = (self.dWh, self.dbh, self.dV, self.dWo, self.dbo)
+        marks = (None, None, self.touched_users, None, None)
+        clear = (True, False, False, False, False)
+        engine.adam_dense_flat([(q.data, g, s["exp_avg"], s["exp_avg_sq"], m, c)
+                                for q, g, s, m, c in zip(self.params, grads, st, marks, clear)],
+                               t, group["lr"], group["betas"][0], group["betas"][1], group["eps"],
+                               group["weight_decay"], decoupled=self.optimizer._decoupled)
+        for s in st:
+            s["step"] = t
+
+    def last_loss(self):
+        """Mean loss of the last step (device scalar)."""
+        return self.stats[0]
+
+    def epoch_loss(self):
+        """Sum of the per-step losses since the last call (what CDAETrainer.train returns); one read-back."""
+        v = float(self.loss_accum.item())
+        self.loss_accum.zero_()
+        return v
+
+    def check(self):
+        engine.raise_on_flag(self.flag, "CDAE")

@@ -164,12 +164,46 @@ struct TileLoader {
   }
 };
 
-template <int BM, int BN, bool TA, bool TB>
+// Optional extras of the tiled kernel (all NULL for a plain GEMM):
+//   count      C gets alpha * (op(A) op(B)), alpha = 1 / *count (0 when the count is 0) — the 1 / (number of
+//              loss positions) factor of a mean loss, known only on the device;
+//   rowsum     rowsum[m] = alpha * sum_k op(A)(m, k), taken from the operand values the MFMAs read anyway (the
+//              bias gradient next to a weight gradient dW = G^T z: no separate column-sum pass over G);
+//   EPI == 1   (decoder of the CDAE training step) y = act(acc + bias), and instead of y the kernel stores the
+//              gradient of the NS-BCE loss w.r.t. the pre-activation, without its 1 / count factor:
+//                  selected (target + negmask != 0):  (y - t) / max((1 - y) y, 1e-12) * act'(y),  else 0
+//              plus one loss partial per workgroup (fixed summation order) and the number of selected positions
+//              (integer atomic: exact, order-free).  `pred` (may be NULL) receives y.
+// The number of loss positions of a step is an integer sum over all decoder workgroups.  One counter would take
+// ~10 k same-address atomics (measured: +90 us on a 40 us kernel); it is spread over YR_COUNT_SLOTS words, one
+// 128-byte line each, and every reader adds the slots up (one 64-lane gather + wave sum).
+constexpr int kCountStride = YR_COUNT_WORDS / YR_COUNT_SLOTS;
+static_assert(YR_COUNT_SLOTS == kWave, "one slot per lane");
+
+__device__ __forceinline__ int32_t spread_count(const int32_t* __restrict__ count, int lane) {
+  int32_t c = count[lane * kCountStride];
+#pragma unroll
+  for (int d = kWave / 2; d >= 1; d >>= 1) c += __shfl_xor(c, d, kWave);
+  return c;
+}
+
+struct GemmExtra {
+  const int32_t* count;
+  float* rowsum;
+  const float* target;
+  const float* negmask;
+  int64_t ldt;
+  float* pred;
+  float* partial_loss;
+  int32_t* count_out;
+};
+
+template <int BM, int BN, bool TA, bool TB, int EPI = 0>
 __global__ __launch_bounds__(kBlock) void gemm_f32_tiled_kernel(const float* __restrict__ A,
                                                                 const float* __restrict__ B, float* __restrict__ C,
                                                                 int M, int N, int K, int64_t lda, int64_t ldb,
                                                                 int64_t ldc, const float* __restrict__ bias, int act,
-                                                                int atomic, int k_per_split) {
+                                                                int atomic, int k_per_split, GemmExtra ex) {
   using LA = TileLoader<BM, !TA>;
   using LB = TileLoader<BN, TB>;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -181,17 +215,46 @@ __global__ __launch_bounds__(kBlock) void gemm_f32_tiled_kernel(const float* __r
   const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
   const int kbeg = blockIdx.z * k_per_split;
   const int kend = min(K, kbeg + k_per_split);
+  const bool want_rowsum = EPI == 0 && ex.rowsum != nullptr;
   f32x16 acc[TM][TN];
+  float rs[TM];
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
+  for (int a = 0; a < TM; ++a) {
+    rs[a] = 0.0f;
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  }
 
   float4 va[LA::NV], vb[LB::NV];
   LA::fetch(A, lda, m0, M, kbeg, kend, va);
   LB::fetch(B, ldb, n0, N, kbeg, kend, vb);
+  // EPI == 1: this lane's target / mask values are fetched now, under the product (they do not depend on it;
+  // loaded one by one in the epilogue, between stores the compiler must assume alias them, they cost a
+  // dependent memory round trip each: 149 us instead of ~50 for the decoder at full size)
+  constexpr int NE = EPI == 1 ? TM * TN * 16 : 1;
+  float tv[NE], mv[NE];
+  if (EPI == 1) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = n0 + wn + b * 32 + i;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = m0 + wm + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          const int e = (b * TM + a) * 16 + reg;
+          const bool in = col < N && row < M;
+          const int64_t at = in ? (int64_t)row * ex.ldt + col : 0;   // clamped address: a plain load, no branch
+          const float t = ex.target[at];
+          const float m = ex.negmask ? ex.negmask[at] : 1.0f;
+          tv[e] = in ? t : 0.0f;
+          mv[e] = in ? m : 0.0f;
+        }
+      }
+    }
+  }
   LA::stash(sA[0], va);
   LB::stash(sB[0], vb);
   __syncthreads();
@@ -212,6 +275,10 @@ __global__ __launch_bounds__(kBlock) void gemm_f32_tiled_kernel(const float* __r
       for (int a = 0; a < TM; ++a) av[a] = a_s[k * LA::P + wm + a * 32 + i];
 #pragma unroll
       for (int b = 0; b < TN; ++b) bv[b] = b_s[k * LB::P + wn + b * 32 + i];
+      if (want_rowsum) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) rs[a] += av[a];
+      }
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -225,27 +292,73 @@ __global__ __launch_bounds__(kBlock) void gemm_f32_tiled_kernel(const float* __r
     buf ^= 1;
   }
 
+  float alpha = 1.0f;
+  if (ex.count) {
+    const int32_t c = spread_count(ex.count, lane);
+    alpha = c > 0 ? 1.0f / (float)c : 0.0f;
+  }
+  if (want_rowsum && blockIdx.y == 0 && (wave & 1) == 0) {       // k even (h = 0) + k odd (h = 1), in this order
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const float other = __shfl_xor(rs[a], 32, kWave);
+      const int row = m0 + wm + a * 32 + i;
+      if (h == 0 && row < M) ex.rowsum[row] = alpha * (rs[a] + other);
+    }
+  }
+
+  float loss = 0.0f;
+  int cnt = 0;
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int col = n0 + wn + b * 32 + i;
-    if (col >= N) continue;
-    const float bvl = (bias && !atomic) ? bias[col] : 0.0f;
+    const bool col_ok = col < N;
+    const float bvl = (bias && !atomic && col_ok) ? bias[col] : 0.0f;
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int row = m0 + wm + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        if (row < M) {
+        if (col_ok && row < M) {
           float* dst = C + (int64_t)row * ldc + col;
-          if (atomic) {
-            atomicAdd(dst, acc[a][b][reg]);
+          if (EPI == 1) {
+            float y = acc[a][b][reg] + bvl;
+            if (act == 1) y = 1.0f / (1.0f + expf(-y));
+            const float t = tv[(b * TM + a) * 16 + reg];
+            const float m = mv[(b * TM + a) * 16 + reg];
+            float g = 0.0f;
+            if (t + m != 0.0f) {
+              loss -= t * fmaxf(logf(y), -100.0f) + (1.0f - t) * fmaxf(logf(1.0f - y), -100.0f);
+              ++cnt;
+              g = (y - t) / fmaxf((1.0f - y) * y, 1e-12f);
+              if (act == 1) g *= y * (1.0f - y);
+            }
+            *dst = g;
+            if (ex.pred) ex.pred[(int64_t)row * ldc + col] = y;
+          } else if (atomic) {
+            atomicAdd(dst, alpha * acc[a][b][reg]);
           } else {
-            float v = acc[a][b][reg] + bvl;
+            float v = alpha * acc[a][b][reg] + bvl;
             if (act == 1) v = 1.0f / (1.0f + expf(-v));
             *dst = v;
           }
         }
       }
+    }
+  }
+  if (EPI == 1) {
+    float* s_red = &sA[0][0];                          // the operand tiles are dead: every wave passed the last barrier
+    const float tl = block_sum(loss, s_red);
+    if (threadIdx.x == 0) ex.partial_loss[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = tl;
+    int c = cnt;
+#pragma unroll
+    for (int d = kWave / 2; d >= 1; d >>= 1) c += __shfl_xor(c, d, kWave);
+    __shared__ int s_cnt[kWavesPerBlock];
+    if (lane == 0) s_cnt[wave] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int tot = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+      const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+      if (tot > 0) atomicAdd(ex.count_out + (wg % YR_COUNT_SLOTS) * kCountStride, tot);
     }
   }
 }
@@ -433,15 +546,86 @@ __global__ __launch_bounds__(kBlock) void nsbce_bwd_kernel(const float* __restri
   }
 }
 
+// One launch for what follows the input-gradient product of the decoder in the CDAE training step:
+//   dz <- dz * act'(z) (in place; dz = G W_o arrives already scaled by 1 / count),
+//   dbh[c] = sum_b dz[b, c]  (wave w of the 16 takes rows w, w + 16, ...; the 16 partial sums are combined in
+//   wave order: deterministic),  dV[user[b], :] += dz[b, :] with the user's row marked in `touched`,
+// and, in one extra workgroup, the loss of the step: stats[0] = (sum of the decoder's per-workgroup
+// partials, fixed order) / count, stats[1] = count, *loss_accum += stats[0].
+constexpr int kHiddenBwdBlock = 1024;
+constexpr int kHiddenBwdWaves = kHiddenBwdBlock / kWave;
+
+__global__ __launch_bounds__(kHiddenBwdBlock) void cdae_hidden_bwd_kernel(
+    float* __restrict__ dz, const float* __restrict__ z, int act, const int64_t* __restrict__ user, int64_t B, int H,
+    int64_t num_users, float* __restrict__ dV, uint8_t* __restrict__ touched, float* __restrict__ dbh,
+    const float* __restrict__ partial_loss, int64_t n_partials, const int32_t* __restrict__ count,
+    float* __restrict__ stats, double* __restrict__ loss_accum, unsigned col_blocks) {
+  __shared__ float s_part[kHiddenBwdWaves][kWave];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (blockIdx.x >= col_blocks) {                    // the loss workgroup
+    float s = 0.0f;
+    for (int64_t k = threadIdx.x; k < n_partials; k += kHiddenBwdBlock) s += partial_loss[k];
+    s = wave_sum(s);
+    if (lane == 0) s_part[wave][0] = s;
+    const int32_t c = spread_count(count, lane);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tot = 0.0f;
+      for (int w = 0; w < kHiddenBwdWaves; ++w) tot += s_part[w][0];
+      const float mean = c > 0 ? tot / (float)c : 0.0f;
+      stats[0] = mean;
+      stats[1] = (float)c;
+      if (loss_accum) loss_accum[0] += (double)mean;
+    }
+    return;
+  }
+  const int c = blockIdx.x * kWave + lane;
+  float acc = 0.0f;
+  if (c < H) {
+    constexpr int U = 8;                               // rows in flight per wave: loads first, then stores / atomics
+    for (int64_t r0 = wave; r0 < B; r0 += U * kHiddenBwdWaves) {
+      float g[U], y[U];
+      int64_t u[U];
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const int64_t r = min(r0 + (int64_t)q * kHiddenBwdWaves, B - 1);
+        g[q] = dz[r * H + c];
+        y[q] = z[r * H + c];
+        u[q] = user[r];
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const int64_t r = r0 + (int64_t)q * kHiddenBwdWaves;
+        if (r >= B) break;
+        if (act == 1) g[q] *= y[q] * (1.0f - y[q]);
+        dz[r * H + c] = g[q];
+        acc += g[q];
+        if ((uint64_t)u[q] < (uint64_t)num_users) {
+          atomicAdd(dV + u[q] * H + c, g[q]);
+          if (touched && c == 0) touched[u[q]] = 1;
+        }
+      }
+    }
+  }
+  s_part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < H) {
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < kHiddenBwdWaves; ++w) t += s_part[w][lane];
+    dbh[c] = t;
+  }
+}
+
 inline int ew_grid(int64_t n) { return grid_for(n, kBlock); }
 
 }  // namespace yr
 
 using namespace yr;
 
-extern "C" int yr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
-                           const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act,
-                           int accumulate, int split_k, void* stream) {
+extern "C" int yr_gemm_f32_ex(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                              const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act,
+                              int accumulate, int split_k, const int32_t* alpha_count, float* rowsum, void* stream) {
   if (M < 0 || N < 0 || K < 0 || M > 0x7fffffff || N > 0x7fffffff || K > 0x7fffffff) return YR_ERR_BADARG;
   if (M == 0 || N == 0) return 0;
   if (!A || !B || !C) return YR_ERR_BADARG;
@@ -453,9 +637,13 @@ extern "C" int yr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
   const int splits = (int)((K + kps - 1) / kps) > 0 ? (int)((K + kps - 1) / kps) : 1;
   const int atomic = (splits > 1 || accumulate) ? 1 : 0;
   if (atomic && (bias || act)) return YR_ERR_BADARG;            // fused epilogue only on a plain store
+  if (rowsum && splits > 1) return YR_ERR_BADARG;               // the row sums come from one pass over all of K
   hipStream_t st = (hipStream_t)stream;
   const bool aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
                        lda % 4 == 0 && ldb % 4 == 0;
+  GemmExtra ex{};
+  ex.count = alpha_count;
+  ex.rowsum = rowsum;
   if (aligned) {
     // largest tile that still gives every CU about eight workgroups; shrink along the dimension
     // with more tiles first (the other operand keeps its reuse)
@@ -470,7 +658,7 @@ extern "C" int yr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
     if (grid.y > 65535 || grid.z > 65535) return YR_ERR_BADARG;
 #define YR_GEMM_LAUNCH(BM, BN, TA, TB)                                                                          \
   hipLaunchKernelGGL((gemm_f32_tiled_kernel<BM, BN, TA, TB>), grid, dim3(kBlock), 0, st, A, B, C, (int)M, (int)N, \
-                     (int)K, lda, ldb, ldc, bias, act, atomic, kps)
+                     (int)K, lda, ldb, ldc, bias, act, atomic, kps, ex)
 #define YR_GEMM_TRANS(BM, BN)                                        \
   do {                                                               \
     if (transA) {                                                    \
@@ -487,11 +675,63 @@ extern "C" int yr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
 #undef YR_GEMM_LAUNCH
     return launch_status();
   }
+  if (alpha_count || rowsum) return YR_ERR_UNSUPPORTED;          // the extras live in the tiled kernel only
   const dim3 grid((unsigned)((N + kGemmTile - 1) / kGemmTile), (unsigned)((M + kGemmTile - 1) / kGemmTile),
                   (unsigned)splits);
   if (grid.y > 65535 || grid.z > 65535) return YR_ERR_BADARG;
   hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(kBlock), 0, st, A, B, C, (int)M, (int)N, (int)K,
                      lda, ldb, ldc, transA ? 1 : 0, transB ? 1 : 0, bias, act, atomic, kps);
+  return launch_status();
+}
+
+extern "C" int yr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                           const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act,
+                           int accumulate, int split_k, void* stream) {
+  return yr_gemm_f32_ex(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, accumulate, split_k, nullptr,
+                        nullptr, stream);
+}
+
+// ---- fused pieces of the CDAE training step (yelprecommendation_amd/cdae_step.py) ----
+constexpr int kDecodeTile = 64;
+
+extern "C" int64_t yr_cdae_decode_loss_partials(int64_t B, int64_t I) {
+  if (B < 0 || I < 0) return YR_ERR_BADARG;
+  return ((B + kDecodeTile - 1) / kDecodeTile) * ((I + kDecodeTile - 1) / kDecodeTile);
+}
+
+extern "C" int yr_cdae_decode_loss(const float* z, const float* Wo, const float* bo, const float* target,
+                                   const float* negative_mask, int64_t B, int64_t I, int H, int act, float* G,
+                                   int64_t ldg, float* pred, float* partial_loss, int32_t* count, void* stream) {
+  if (B < 0 || I < 0 || H <= 0 || B > 0x7fffffff || I > 0x7fffffff) return YR_ERR_BADARG;
+  if (act != 0 && act != 1) return YR_ERR_UNSUPPORTED;
+  if (B == 0 || I == 0) return 0;
+  if (!z || !Wo || !target || !G || !partial_loss || !count || ldg < I) return YR_ERR_BADARG;
+  if (((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(Wo)) & 15) || H % 4) return YR_ERR_BADARG;
+  const dim3 grid((unsigned)((B + kDecodeTile - 1) / kDecodeTile), (unsigned)((I + kDecodeTile - 1) / kDecodeTile), 1);
+  if (grid.y > 65535) return YR_ERR_BADARG;
+  GemmExtra ex{};
+  ex.target = target;
+  ex.negmask = negative_mask;
+  ex.ldt = I;
+  ex.pred = pred;
+  ex.partial_loss = partial_loss;
+  ex.count_out = count;
+  hipLaunchKernelGGL((gemm_f32_tiled_kernel<kDecodeTile, kDecodeTile, false, true, 1>), grid, dim3(kBlock), 0,
+                     (hipStream_t)stream, z, Wo, G, (int)B, (int)I, H, (int64_t)H, (int64_t)H, ldg, bo, act, 0, H, ex);
+  return launch_status();
+}
+
+extern "C" int yr_cdae_hidden_bwd(float* dz, const float* z, int act, const int64_t* user, int64_t B, int H,
+                                  int64_t num_users, float* dV, uint8_t* touched_users, float* dbh,
+                                  const float* partial_loss, int64_t n_partials, const int32_t* count, float* stats,
+                                  double* loss_accum, void* stream) {
+  if (B < 0 || H <= 0 || num_users <= 0 || n_partials < 0 || (act != 0 && act != 1)) return YR_ERR_BADARG;
+  if (!dz || !z || !user || !dV || !dbh) return YR_ERR_BADARG;
+  if (n_partials > 0 && (!partial_loss || !count || !stats)) return YR_ERR_BADARG;
+  const unsigned col_blocks = (unsigned)((H + kWave - 1) / kWave);
+  hipLaunchKernelGGL(cdae_hidden_bwd_kernel, dim3(col_blocks + (n_partials > 0 ? 1u : 0u)), dim3(kHiddenBwdBlock), 0,
+                     (hipStream_t)stream, dz, z, act, user, B, H, num_users, dV, touched_users, dbh, partial_loss,
+                     n_partials, count, stats, loss_accum, col_blocks);
   return launch_status();
 }
 

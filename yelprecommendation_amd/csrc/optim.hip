@@ -135,6 +135,71 @@ __global__ __launch_bounds__(kBlock) void adam_dual_kernel(DualAdam t, AdamScala
   }
 }
 
+// Up to YR_ADAM_MULTI_MAX tensors of any size in ONE launch, 16 bytes per lane (every buffer 16-byte aligned;
+// the 1-3 elements after the last whole float4 of a tensor are done by one lane).  The work is cut into chunks of kBlock float4 that never straddle two tensors,
+// so the tensor a workgroup iteration works on is wave-uniform (its pointers stay in scalar registers).
+// Per tensor:
+//   touched[k] != NULL  one byte per row of row4[k] float4: the gradient of a row is read — and cleared, with
+//                       its mark — only where the step touched it (dense Adam semantics: every row is updated,
+//                       with grad = 0 where nothing arrived); the gradient buffer stays all-zero between steps;
+//   clear[k] != 0       the gradient is cleared after it is read (a buffer the next step accumulates into).
+struct AdamFlat {
+  float4* p[YR_ADAM_MULTI_MAX];
+  float4* g[YR_ADAM_MULTI_MAX];
+  float4* m[YR_ADAM_MULTI_MAX];
+  float4* v[YR_ADAM_MULTI_MAX];
+  uint8_t* touched[YR_ADAM_MULTI_MAX];
+  int64_t n4[YR_ADAM_MULTI_MAX];
+  int64_t chunk_end[YR_ADAM_MULTI_MAX];  // running end of tensor k in chunks
+  int row4[YR_ADAM_MULTI_MAX];
+  int clear[YR_ADAM_MULTI_MAX];
+  int tail[YR_ADAM_MULTI_MAX];           // n % 4
+  int count;
+};
+
+template <bool DECOUPLED>
+__global__ __launch_bounds__(kBlock) void adam_flat_kernel(AdamFlat t, AdamScalars c) {
+  const int64_t chunks = t.chunk_end[t.count - 1];
+  for (int64_t ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+    int k = 0;
+    for (int q = 0; q + 1 < t.count; ++q)
+      if (ch >= t.chunk_end[q]) k = q + 1;
+    const int64_t j = (ch - (k > 0 ? t.chunk_end[k - 1] : 0)) * kBlock + threadIdx.x;
+    if (j >= t.n4[k]) {
+      if (j == t.n4[k] && t.tail[k]) {                // the 1-3 elements after the last whole float4
+        float* p = reinterpret_cast<float*>(t.p[k] + j);
+        float* g = reinterpret_cast<float*>(t.g[k] + j);
+        float* m = reinterpret_cast<float*>(t.m[k] + j);
+        float* v = reinterpret_cast<float*>(t.v[k] + j);
+        for (int e = 0; e < t.tail[k]; ++e) {
+          adam_element<DECOUPLED>(p[e], g[e], m[e], v[e], c);
+          if (t.clear[k]) g[e] = 0.0f;
+        }
+      }
+      continue;
+    }
+    float4* gp = t.g[k];
+    uint8_t* tp = t.touched[k];
+    const int row4 = t.row4[k];
+    float4 P = t.p[k][j], M = t.m[k][j], V = t.v[k][j];
+    float4 G = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t row = tp ? j / row4 : 0;
+    const bool has = tp ? tp[row] != 0 : true;
+    if (has) {
+      G = gp[j];
+      if (tp || t.clear[k]) gp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tp && j % row4 == 0) tp[row] = 0;           // after every lane of the row (same wave) has read the mark
+    }
+    adam_element<DECOUPLED>(P.x, G.x, M.x, V.x, c);
+    adam_element<DECOUPLED>(P.y, G.y, M.y, V.y, c);
+    adam_element<DECOUPLED>(P.z, G.z, M.z, V.z, c);
+    adam_element<DECOUPLED>(P.w, G.w, M.w, V.w, c);
+    t.p[k][j] = P;
+    t.m[k][j] = M;
+    t.v[k][j] = V;
+  }
+}
+
 template <bool ZERO_GRAD>
 __global__ __launch_bounds__(kBlock) void sgd_dense_kernel(float* __restrict__ p, float* __restrict__ g,
                                                            int64_t n4, int64_t n, float lr, float wd) {
@@ -282,6 +347,54 @@ extern "C" int yr_adam_dense_multi(float* const* p, float* const* g, float* cons
     if (zero_grad) YR_LAUNCH_ADAM_MULTI(false, true); else YR_LAUNCH_ADAM_MULTI(false, false);
   }
 #undef YR_LAUNCH_ADAM_MULTI
+  return launch_status();
+}
+
+extern "C" int yr_adam_dense_flat(float* const* p, float* const* g, float* const* m, float* const* v,
+                                  const int64_t* n, uint8_t* const* touched, const int* row_width, const int* clear,
+                                  int count, double lr, double step_size, double bc2_sqrt, double beta1, double beta2,
+                                  double eps, double weight_decay, int mode, void* stream) {
+  if (count < 0 || count > YR_ADAM_MULTI_MAX) return YR_ERR_BADARG;
+  if (count == 0) return 0;
+  if (!p || !g || !m || !v || !n) return YR_ERR_BADARG;
+  if (mode != YR_OPT_ADAM && mode != YR_OPT_ADAMW) return YR_ERR_UNSUPPORTED;
+  AdamFlat t{};
+  int64_t chunks = 0;
+  int used = 0;
+  for (int k = 0; k < count; ++k) {
+    if (n[k] < 0) return YR_ERR_BADARG;
+    if (n[k] == 0) continue;
+    if (!p[k] || !g[k] || !m[k] || !v[k]) return YR_ERR_BADARG;
+    if (!aligned16(p[k]) || !aligned16(g[k]) || !aligned16(m[k]) || !aligned16(v[k])) return YR_ERR_BADARG;
+    uint8_t* tp = touched ? touched[k] : nullptr;
+    const int rw = row_width ? row_width[k] : 0;
+    // the lanes of a marked row must sit in one wave (they all read the mark before one of them clears it)
+    if (tp && (rw <= 0 || (rw & 3) || n[k] % rw || rw / 4 > kWave || kWave % (rw / 4))) return YR_ERR_BADARG;
+    t.p[used] = (float4*)p[k]; t.g[used] = (float4*)g[k]; t.m[used] = (float4*)m[k]; t.v[used] = (float4*)v[k];
+    t.touched[used] = tp;
+    t.row4[used] = tp ? rw / 4 : 1;
+    t.clear[used] = clear ? clear[k] : 0;
+    t.n4[used] = n[k] / 4;
+    t.tail[used] = (int)(n[k] & 3);
+    chunks += (n[k] / 4 + (t.tail[used] ? 1 : 0) + kBlock - 1) / kBlock;   // one more lane for the tail
+    t.chunk_end[used] = chunks;
+    ++used;
+  }
+  if (used == 0) return 0;
+  t.count = used;
+  AdamScalars c;
+  c.decay_mul = (float)(1.0 - lr * weight_decay);
+  c.neg_step = (float)(-step_size);
+  c.bc2_sqrt = (float)bc2_sqrt;
+  c.one_m_b1 = (float)(1.0 - beta1);
+  c.beta2 = (float)beta2;
+  c.one_m_b2 = (float)(1.0 - beta2);
+  c.eps = (float)eps;
+  c.wd = (float)weight_decay;
+  const int grid = (int)(chunks < kMaxGrid ? chunks : kMaxGrid);
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == YR_OPT_ADAMW) hipLaunchKernelGGL((adam_flat_kernel<true>), dim3(grid), dim3(kBlock), 0, s, t, c);
+  else hipLaunchKernelGGL((adam_flat_kernel<false>), dim3(grid), dim3(kBlock), 0, s, t, c);
   return launch_status();
 }
 

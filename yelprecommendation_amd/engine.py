@@ -42,6 +42,14 @@ def _dev(t: torch.Tensor, dtype, name: str) -> int:
     return t.data_ptr()
 
 
+def _rows(t: torch.Tensor, dtype, name: str) -> int:
+    """A 2-D row-major operand whose rows may be views into a wider buffer (stride(1) == 1)."""
+    if isinstance(t, torch.Tensor) and t.dim() == 2 and t.is_cuda and t.dtype == dtype and t.stride(1) == 1 \
+            and t.stride(0) >= t.shape[1]:
+        return t.data_ptr()
+    return _dev(t, dtype, name)
+
+
 def _opt(t, dtype, name):
     return None if t is None else _dev(t, dtype, name)
 
@@ -311,12 +319,15 @@ def ngcf_dense_bwd(dEout, Eout, E, Z, W1, W2, dE, dW1, dW2, dZ=None, W1T=None, W
 
 
 ACT_IDENTITY, ACT_SIGMOID = 0, 1
+COUNT_WORDS, COUNT_SLOTS = 2048, 64        # include/yelprec_engine.h YR_COUNT_WORDS / YR_COUNT_SLOTS
 
 
 def gemm_f32(A, B, transA=False, transB=False, out=None, bias=None, act=ACT_IDENTITY, accumulate=False,
-             split_k=1):
+             split_k=1, alpha_count=None, rowsum=None):
     """out (+)= op(A) @ op(B) on the f32 matrix cores.  A, B 2-D row-major f32 GPU tensors;
-    ``transA``: use A^T, ``transB``: use B^T (nn.Linear's ``x @ W^T`` is ``transB=True``)."""
+    ``transA``: use A^T, ``transB``: use B^T (nn.Linear's ``x @ W^T`` is ``transB=True``).
+    ``alpha_count`` (spread int32 count, COUNT_WORDS words): the product is scaled by 1 / count; ``rowsum`` ([M] f32): receives
+    alpha * the row sums of op(A) (yr_gemm_f32_ex)."""
     lib = _lib.load()
     f32 = torch.float32
     M, K = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
@@ -329,11 +340,70 @@ def gemm_f32(A, B, transA=False, transB=False, out=None, bias=None, act=ACT_IDEN
         out = (torch.zeros if split_k > 1 else torch.empty)((M, N), dtype=f32, device=A.device)
     if out.shape != (M, N) or out.stride(1) != 1:
         raise EngineError("bad output buffer")
-    check(lib.yr_gemm_f32(1 if transA else 0, 1 if transB else 0, M, N, K, _dev(A, f32, "A"), A.stride(0),
-                          _dev(B, f32, "B"), B.stride(0), out.data_ptr(), out.stride(0),
+    if alpha_count is not None and alpha_count.numel() != COUNT_WORDS:
+        raise EngineError(f"alpha_count: a spread count of {COUNT_WORDS} int32 words")
+    if alpha_count is not None or rowsum is not None:
+        if rowsum is not None and rowsum.numel() != M:
+            raise EngineError("rowsum needs one element per row of op(A)")
+        check(lib.yr_gemm_f32_ex(1 if transA else 0, 1 if transB else 0, M, N, K, _rows(A, f32, "A"), A.stride(0),
+                                 _rows(B, f32, "B"), B.stride(0), out.data_ptr(), out.stride(0),
+                                 _opt(bias, f32, "bias"), int(act), 1 if accumulate else 0, int(split_k),
+                                 _opt(alpha_count, torch.int32, "alpha_count"), _opt(rowsum, f32, "rowsum"),
+                                 _stream()), "yr_gemm_f32_ex")
+        return out
+    check(lib.yr_gemm_f32(1 if transA else 0, 1 if transB else 0, M, N, K, _rows(A, f32, "A"), A.stride(0),
+                          _rows(B, f32, "B"), B.stride(0), out.data_ptr(), out.stride(0),
                           _opt(bias, f32, "bias"), int(act), 1 if accumulate else 0, int(split_k), _stream()),
           "yr_gemm_f32")
     return out
+
+
+def spread_count(value, device):
+    """A spread count holding ``value`` (tests; the kernels fill it with atomics)."""
+    c = torch.zeros(COUNT_WORDS, dtype=torch.int32, device=device)
+    c[0] = int(value)
+    return c
+
+
+def cdae_decode_loss_partials(B, I):
+    return int(_lib.load().yr_cdae_decode_loss_partials(int(B), int(I)))
+
+
+def cdae_decode_loss(z, Wo, bo, target, negative_mask, act, G, partial_loss, count, pred=None):
+    """Decoder of the CDAE training step with the NS-BCE / BCE loss in its epilogue (yr_cdae_decode_loss):
+    G = d loss / d pre-activation without the 1 / count factor, per-workgroup loss partials, count of the
+    selected positions (``count`` must be zero on entry)."""
+    lib = _lib.load()
+    f32 = torch.float32
+    B, H = z.shape
+    I = Wo.shape[0]
+    if partial_loss.numel() < cdae_decode_loss_partials(B, I) or G.shape != (B, I) or target.shape != (B, I):
+        raise EngineError("bad buffers for cdae_decode_loss")
+    if count.numel() != COUNT_WORDS:
+        raise EngineError(f"count: a spread count of {COUNT_WORDS} int32 words")
+    if pred is not None and (pred.shape != G.shape or pred.stride() != G.stride()):
+        raise EngineError("pred must have the layout of G")
+    check(lib.yr_cdae_decode_loss(_dev(z, f32, "z"), _dev(Wo, f32, "Wo"), _opt(bo, f32, "bo"),
+                                  _dev(target, f32, "target"), _opt(negative_mask, f32, "negative_mask"), B, I, H,
+                                  int(act), _rows(G, f32, "G"), G.stride(0),
+                                  None if pred is None else _rows(pred, f32, "pred"),
+                                  _dev(partial_loss, f32, "partial_loss"), _dev(count, torch.int32, "count"),
+                                  _stream()), "yr_cdae_decode_loss")
+    return G
+
+
+def cdae_hidden_bwd(dz, z, act, user, dV, touched_users, dbh, partial_loss=None, n_partials=0, count=None,
+                    stats=None, loss_accum=None):
+    """dz <- dz * act'(z); dbh = column sums; dV[user] += dz (rows marked in ``touched_users``); with
+    ``n_partials`` > 0 also the loss of the step into ``stats`` / ``loss_accum`` (yr_cdae_hidden_bwd)."""
+    lib = _lib.load()
+    f32 = torch.float32
+    B, H = dz.shape
+    check(lib.yr_cdae_hidden_bwd(_dev(dz, f32, "dz"), _dev(z, f32, "z"), int(act), _dev(user, torch.int64, "user"),
+                                 B, H, dV.shape[0], _dev(dV, f32, "dV"), _opt(touched_users, torch.uint8, "touched"),
+                                 _dev(dbh, f32, "dbh"), _opt(partial_loss, f32, "partial_loss"), int(n_partials),
+                                 _opt(count, torch.int32, "count"), _opt(stats, f32, "stats"),
+                                 _opt(loss_accum, torch.float64, "loss_accum"), _stream()), "yr_cdae_hidden_bwd")
 
 
 def cdae_hidden_init(bias, V, user, err_flag=None):
@@ -363,7 +433,7 @@ class SparseRows:
     the list buffers are sized for the worst case once per batch shape and reused by the next call."""
     _pool = {}
 
-    def __init__(self, x, seed=0, p=0.0):
+    def __init__(self, x, seed=0, p=0.0, count=None):
         lib = _lib.load()
         B, I = x.shape
         self.cpp = int(lib.yr_cdae_sparse_part_columns(I))
@@ -374,7 +444,7 @@ class SparseRows:
             buf = (torch.empty(n, dtype=torch.int32, device=x.device), torch.empty(n, dtype=torch.float32, device=x.device))
             SparseRows._pool = {key: buf}                  # one batch shape at a time
         self.cols, self.vals = buf
-        self.count = torch.empty(B * SPARSE_PARTS, dtype=torch.int32, device=x.device)
+        self.count = torch.empty(B * SPARSE_PARTS, dtype=torch.int32, device=x.device) if count is None else count
         self.B, self.I = B, I
         check(lib.yr_cdae_compact_rows(_dev(x, torch.float32, "x"), B, I, int(seed) & (2**64 - 1), float(p),
                                        self.cols.data_ptr(), self.vals.data_ptr(), self.count.data_ptr(), _stream()),
@@ -396,11 +466,11 @@ class SparseRows:
         return torch.cat([c[q, :int(n[q])] for q in range(SPARSE_PARTS)])
 
 
-def cdae_sparse_encode(rows: "SparseRows", Wh, bh, V, user, act, err_flag=None):
+def cdae_sparse_encode(rows: "SparseRows", Wh, bh, V, user, act, err_flag=None, out=None):
     """z = act(Wh . rows + bh + V[user])   (reference models/cdae.py:49, sparse input)."""
     lib = _lib.load()
     H = Wh.shape[0]
-    z = torch.empty(rows.B, H, dtype=torch.float32, device=Wh.device)
+    z = torch.empty(rows.B, H, dtype=torch.float32, device=Wh.device) if out is None else out
     check(lib.yr_cdae_sparse_encode(rows.cols.data_ptr(), rows.vals.data_ptr(), rows.count.data_ptr(),
                                     _dev(Wh, torch.float32, "Wh"), _dev(bh, torch.float32, "bh"),
                                     _dev(V, torch.float32, "V"), _dev(user, torch.int64, "user"), rows.B, rows.I, H,
@@ -732,6 +802,31 @@ def adam_dense_multi(tensors, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight
                                       float(step_size), float(bc2_sqrt), float(beta1), float(beta2), float(eps),
                                       float(weight_decay), OPT_ADAMW if decoupled else OPT_ADAM,
                                       1 if zero_grad else 0, _stream()), "yr_adam_dense_multi")
+
+
+def adam_dense_flat(tensors, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, decoupled=False):
+    """One launch, 16 bytes per lane, for up to ADAM_MULTI_MAX tensors of any size (yr_adam_dense_flat).
+    ``tensors``: (p, g, m, v, touched, clear) — ``touched`` a uint8 mark per row of p (or None), ``clear`` whether
+    the gradient is zeroed after it is read."""
+    import ctypes
+    lib = _lib.load()
+    if len(tensors) > ADAM_MULTI_MAX:
+        raise EngineError(f"at most {ADAM_MULTI_MAX} tensors per launch")
+    step_size, bc2_sqrt = adam_scalars(step, lr, beta1, beta2)
+    f32 = torch.float32
+    n = len(tensors)
+    cols = [(ctypes.c_void_p * n)(*[_dev(t[k], f32, name) for t in tensors]) for k, name in enumerate("pgmv")]
+    for t in tensors:
+        if not (t[0].numel() == t[1].numel() == t[2].numel() == t[3].numel()):
+            raise EngineError("p/g/m/v sizes differ")
+    counts = (ctypes.c_int64 * n)(*[t[0].numel() for t in tensors])
+    marks = (ctypes.c_void_p * n)(*[_opt(t[4], torch.uint8, "touched") for t in tensors])
+    widths = (ctypes.c_int * n)(*[int(t[0].shape[-1]) if t[4] is not None else 0 for t in tensors])
+    clear = (ctypes.c_int * n)(*[1 if t[5] else 0 for t in tensors])
+    check(lib.yr_adam_dense_flat(cols[0], cols[1], cols[2], cols[3], counts, marks, widths, clear, n, float(lr),
+                                 float(step_size), float(bc2_sqrt), float(beta1), float(beta2), float(eps),
+                                 float(weight_decay), OPT_ADAMW if decoupled else OPT_ADAM, _stream()),
+          "yr_adam_dense_flat")
 
 
 def sgd_dense(p, g, lr, weight_decay=0.0, zero_grad=False):

@@ -16,6 +16,7 @@ import torch
 from .. import engine
 from ..loss import BCELoss, NSBCELoss
 from ..metric import ranking_metrics
+from ..cdae_step import CDAEStep
 from ..models.cdae import CDAE
 from ..utils import log_metric, logger
 from .base_trainer import BaseTrainer
@@ -29,6 +30,7 @@ class CDAETrainer(BaseTrainer):
         self.loss = self._loss()
         self._loss_accum = torch.zeros(1, dtype=torch.float64, device=self.device)
         self._partials = torch.zeros(engine.LOSS_PARTIALS, dtype=torch.float32, device=self.device)
+        self._step = None                                  # the CDAEStep, kept across epochs
 
     def _loss(self):
         # reference cdae_trainer.py:26-33
@@ -44,9 +46,39 @@ class CDAETrainer(BaseTrainer):
         self._partials[:1].copy_(loss.detach().reshape(1))
         engine.loss_finalize(self._partials, 1.0, None, self._loss_accum)
 
+    def _fused_step(self):
+        """The CDAEStep bound to the model's parameters and the optimizer's Adam state (cdae_step.py), or None
+        when the optimizer is not Adam / AdamW or ``cfg.fused_step`` is off — training then goes through the
+        model's autograd node, the loss module and optimizer.step(), launch by launch."""
+        from .. import optim
+        if not self.cfg.get("fused_step", True) or not isinstance(self.optimizer, optim.Adam):
+            return None
+        if self.model.hidden_size % 4:                     # 16-byte rows for the matrix-core operands
+            return None
+        if self._step is None or not self._step.bound_to(self.model, self.optimizer):
+            self._step = CDAEStep(self.model, self.optimizer, self.cfg.negative_sampling)
+        return self._step
+
     def train(self, train_dataloader) -> float:
         # reference cdae_trainer.py:36-54
         self.model.train()
+        step = self._fused_step()
+        if step is not None:
+            model = self.model
+            own_noise = "add_noise" not in model.__dict__ and type(model).add_noise is CDAE.add_noise
+            step.loss_accum.zero_()
+            for data in train_dataloader:
+                user_id, input_mask = data['user_id'].to(self.device), data['input_mask'].to(self.device)
+                negative_mask = data['negative_mask'].to(self.device) if self.cfg.negative_sampling else None
+                if own_noise:
+                    # the seed draw of CDAE.forward (same position in torch's generator stream)
+                    p = model.corruption_level
+                    seed = int(torch.randint(0, 1 << 62, (1,)).item()) if p > 0 else 0
+                    step.step(user_id, input_mask, negative_mask, seed=seed, p=p)
+                else:                                       # an overridden add_noise (tests replay recorded masks)
+                    step.step(user_id, input_mask, negative_mask, x_in=model.add_noise(input_mask))
+            step.check()
+            return step.epoch_loss()
         self._loss_accum.zero_()
         for data in train_dataloader:
             user_id, input_mask = data['user_id'].to(self.device), data['input_mask'].to(self.device)
