@@ -295,7 +295,7 @@ int yr_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K,
  *   spread over its slots.  pred (may be NULL)
  *   receives y.  z / Wo 16-byte aligned, H a multiple of 4; ldg >= I = leading dimension of G and pred (a
  *   multiple of 4 lets the gradient products that read G take the tiled kernel).
- * yr_cdae_hidden_bwd: dz <- dz * act'(z) in place, dbh = column sums, dV[user[b],:] += dz[b,:] with
+ * yr_cdae_hidden_bwd: dz <- dz * act'(z) in place (scale_dz != 0: dz / count first), dbh = column sums, dV[user[b],:] += dz[b,:] with
  *   touched_users[user[b]] = 1 (may be NULL); with n_partials > 0 also the step's loss: stats[0] = (sum of
  *   partial_loss in fixed order) / count, stats[1] = count, *loss_accum += stats[0] (may be NULL). */
 int yr_gemm_f32_ex(int transA, int transB, int64_t M, int64_t N, int64_t K,
@@ -309,7 +309,27 @@ int yr_cdae_decode_loss(const float *z, const float *Wo, const float *bo, const 
 int yr_cdae_hidden_bwd(float *dz, const float *z, int act, const int64_t *user, int64_t B, int H,
                        int64_t num_users, float *dV, uint8_t *touched_users, float *dbh,
                        const float *partial_loss, int64_t n_partials, const int32_t *count,
-                       float *stats, double *loss_accum, void *stream);
+                       float *stats, double *loss_accum, int scale_dz, void *stream);
+/* The decoder of a TRAINING step on the loss positions only (NSBCELoss reads the prediction where
+ * target + negative_mask != 0 and nowhere else — loss.py:14-16 — so its gradient w.r.t. every other position
+ * is exactly zero and the three dense decoder products reduce to a pass over the position lists):
+ * yr_cdae_compact_pair: yr_cdae_compact_rows (lists of dropout_p(x), the encoder's input) and, from the same
+ *   pass over x and negative_mask, the loss positions of every row as (column, target) lists in the same
+ *   32-sub-list layout (loss_cols / loss_targets / loss_count sized like cols / vals / count).
+ * yr_cdae_sampled_decode: per position (b, i): y = act(z[b] . W_o[i] + b_o[i]), its BCE term (clamped at -100)
+ *   into partial_loss[b * yr_cdae_sampled_decode_splits() + s] (fixed order), g = (y - t) / max((1 - y) y,
+ *   1e-12) * act'(y), then dz[b,:] += g W_o[i,:] (dz zero on entry), dW_o[i,:] += g z[b,:], db_o[i] += g
+ *   (float atomics; both buffers zero on entry where untouched), touched_items[i] = 1, count (spread,
+ *   YR_COUNT_WORDS, zero on entry) += positions.  Nothing carries the 1 / count of the mean: the consumers apply
+ *   it (yr_cdae_hidden_bwd scale_dz = 1, yr_adam_dense_flat scaled[k] = 1).  H a multiple of 4, <= 256. */
+int yr_cdae_compact_pair(const float *x, const float *negative_mask, int64_t B, int64_t I, uint64_t seed,
+                         double p, int32_t *cols, float *vals, int32_t *count, int32_t *loss_cols,
+                         float *loss_targets, int32_t *loss_count, void *stream);
+int yr_cdae_sampled_decode_splits(void);
+int yr_cdae_sampled_decode(const int32_t *loss_cols, const float *loss_targets, const int32_t *loss_count,
+                           const float *z, const float *Wo, const float *bo, int64_t B, int64_t I, int H,
+                           int act, float *dz, float *dWo, float *dbo, uint8_t *touched_items,
+                           float *partial_loss, int32_t *count, void *stream);
 int yr_cdae_hidden_init(float *zpre, const float *bias, const float *V, const int64_t *user,
                         int64_t B, int H, int64_t num_users, int32_t *err_flag, void *stream);
 int yr_dropout(const float *x, const float *rnd, double p, int64_t n, float *out, void *stream);
@@ -436,10 +456,11 @@ int yr_adam_dense_multi(float *const *p, float *const *g, float *const *m, float
  * (every buffer 16-byte aligned).  touched[k] (HOST array of device pointers,
  * entries may be NULL): one byte per row of row_width[k] floats (row_width / 4 a power of two <= 64) — the
  * gradient of a row is read, cleared and unmarked only where the mark is set (every row is still updated, with
- * grad = 0 elsewhere).  clear[k] != 0: the gradient is cleared after it is read. */
+ * grad = 0 elsewhere).  clear[k] != 0: the gradient is cleared after it is read.  scaled[k] != 0 (with
+ * grad_count, a spread count, see YR_COUNT_SLOTS): the gradient is multiplied by 1 / count first. */
 int yr_adam_dense_flat(float *const *p, float *const *g, float *const *m, float *const *v,
                        const int64_t *n, uint8_t *const *touched, const int *row_width, const int *clear,
-                       int count, double lr, double step_size, double bc2_sqrt, double beta1,
+                       const int *scaled, const int32_t *grad_count, int count, double lr, double step_size, double bc2_sqrt, double beta1,
                        double beta2, double eps, double weight_decay, int mode, void *stream);
 int yr_sgd_dense(float *p, float *g, int64_t n, double lr, double weight_decay,
                  int zero_grad, void *stream);

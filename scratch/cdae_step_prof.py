@@ -37,8 +37,9 @@ def auto():
 
 if mode in ("both", "auto"):
     print("autograd route  %.4f ms" % timed(auto), flush=True)
-if mode in ("both", "fused"):
-    step = CDAEStep(model, opt)
+if mode in ("both", "fused", "dense", "sampled"):
+    step = CDAEStep(model, opt, decoder="auto" if mode in ("both", "fused") else mode)
+    print("decoder", step.decoder)
     k = [0]
 
     def fused():

@@ -165,14 +165,14 @@ def test_seeded_dropout_is_a_fair_reproducible_mask(device):
     assert torch.equal(m1, m2) and not torch.equal(m1, m3)
 
 
-@pytest.mark.parametrize("fused_step", [True, False])
+@pytest.mark.parametrize("fused_step", ["sampled", "dense", False])
 def test_trainer_run_matches_reference(g, tmp_path, device, fused_step):
     """The reference's recorded run, once through the fused step (cdae_step.py, the default) and once launch by
     launch through autograd (model node + loss module + optimizer.step)."""
     from yelprecommendation_amd.trainers import CDAETrainer
-    t = CDAETrainer(_cfg(g, tmp_path, negative_sampling=True, fused_step=fused_step), int(g["num_items"]),
-                    int(g["num_users"]))
-    assert (t._fused_step() is not None) == fused_step
+    t = CDAETrainer(_cfg(g, tmp_path, negative_sampling=True, fused_step=bool(fused_step),
+                         train_decoder=fused_step or "auto"), int(g["num_items"]), int(g["num_users"]))
+    assert (t._fused_step().decoder if fused_step else t._fused_step()) == (fused_step or None)
     _load(t.model, g, "init")
     X = g["train_input"].astype(np.float32)
     VM = g["valid_mask"].astype(np.float32)
@@ -424,9 +424,11 @@ def test_adam_flat_equals_adam_dense(device):
         assert float(G[0].abs().sum()) == 0.0 and float(G[3].abs().sum()) > 0.0     # clear flag / left alone
 
 
-@pytest.mark.parametrize("ni,negative_sampling", [(1501, True), (1504, True), (1503, False)])
-def test_fused_step_equals_autograd_route(device, tmp_path, ni, negative_sampling):
-    """cdae_step.CDAEStep (decoder with the loss in its epilogue, count-scaled gradient products, one Adam launch)
+@pytest.mark.parametrize("ni,negative_sampling,decoder", [(1501, True, "dense"), (1504, True, "sampled"),
+                                                          (1501, True, "sampled"), (1503, False, "dense")])
+def test_fused_step_equals_autograd_route(device, tmp_path, ni, negative_sampling, decoder):
+    """cdae_step.CDAEStep — dense decoder (loss in the GEMM epilogue, count-scaled gradient products) and sampled
+    decoder (forward, loss and decoder gradients on the loss positions only), one Adam launch —
     against the autograd route (model + loss module + optimizer.step) over four steps from the same init, with
     the same dropout seeds: losses, all parameters, all Adam moments.  Ragged catalogue widths, duplicate users,
     an all-zero row; NS-BCE and plain BCE; then both against the NumPy oracle for the first step."""
@@ -452,12 +454,16 @@ def test_fused_step_equals_autograd_route(device, tmp_path, ni, negative_samplin
         opt = Adam(model.parameters(), lr=1e-3)
         losses = []
         if fused:
-            step = CDAEStep(model, opt, negative_sampling)
+            step = CDAEStep(model, opt, negative_sampling, decoder=decoder)
+            assert step.decoder == decoder
             for u, x, neg, seed in batches:
                 step.step(t(u), t(x), t(neg) if negative_sampling else None, seed=seed, p=model.corruption_level)
                 losses.append(float(step.last_loss()))
             assert abs(step.epoch_loss() - sum(losses)) < 1e-5 and float(step.dV.abs().sum()) == 0.0 \
                 and float(step.dWh.abs().sum()) == 0.0
+            if decoder == "sampled":                                  # consumed gradients are cleared, marks reset
+                assert float(step.dWo.abs().sum()) == 0.0 and float(step.dbo.abs().sum()) == 0.0 \
+                    and int(step.touched_items.sum()) == 0
             step.check()
         else:
             lossf = NSBCELoss() if negative_sampling else BCELoss()
@@ -482,7 +488,7 @@ def test_fused_step_equals_autograd_route(device, tmp_path, ni, negative_samplin
     u, x, neg, seed = batches[0]
     xin = engine_dropout(t(x), seed, model.corruption_level).cpu().numpy()
     want = float(ref.train_step(u, xin, x, neg if negative_sampling else np.ones_like(x)))
-    step = CDAEStep(model, Adam(model.parameters(), lr=1e-3), negative_sampling)
+    step = CDAEStep(model, Adam(model.parameters(), lr=1e-3), negative_sampling, decoder=decoder)
     step.step(t(u), t(x), t(neg) if negative_sampling else None, seed=seed, p=model.corruption_level)
     np.testing.assert_allclose(float(step.last_loss()), want, rtol=1e-5)
     for p, r in zip(model.parameters(), ref.params):

@@ -143,11 +143,12 @@ def test_cdae_full_size_step_matches_oracle(device, tmp_path):
         np.testing.assert_allclose(p.detach().cpu().numpy(), r, rtol=1e-3, atol=2e-6, err_msg=name)
     # the fused step (cdae_step.py) from the same init on the same batch: same loss, same parameters
     from yelprecommendation_amd.cdae_step import CDAEStep
-    torch.manual_seed(2)
-    model2 = CDAE(cfg, NI, NU)
-    step = CDAEStep(model2, Adam(model2.parameters(), lr=1e-3))
-    step.step(t(u), t(x), t(neg), x_in=t(xin))
-    np.testing.assert_allclose(float(step.last_loss()), want, rtol=1e-5)
-    for (name, p), r in zip(model2.named_parameters(), ref.params):
-        np.testing.assert_allclose(p.detach().cpu().numpy(), r, rtol=1e-3, atol=2e-6, err_msg="fused " + name)
-    step.check()
+    for decoder in ("sampled", "dense"):
+        torch.manual_seed(2)
+        model2 = CDAE(cfg, NI, NU)
+        step = CDAEStep(model2, Adam(model2.parameters(), lr=1e-3), decoder=decoder)
+        step.step(t(u), t(x), t(neg), x_in=t(xin))
+        np.testing.assert_allclose(float(step.last_loss()), want, rtol=1e-5)
+        for (name, p), r in zip(model2.named_parameters(), ref.params):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), r, rtol=1e-3, atol=2e-6, err_msg=f"{decoder} {name}")
+        step.check()

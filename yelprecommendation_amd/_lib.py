@@ -46,7 +46,10 @@ SIGNATURES = {
     "yr_gemm_f32_ex": [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _int, _int, _int, _p, _p, _p],
     "yr_cdae_decode_loss_partials": [_i64, _i64],
     "yr_cdae_decode_loss": [_p, _p, _p, _p, _p, _i64, _i64, _int, _int, _p, _i64, _p, _p, _p, _p],
-    "yr_cdae_hidden_bwd": [_p, _p, _int, _p, _i64, _int, _i64, _p, _p, _p, _p, _i64, _p, _p, _p, _p],
+    "yr_cdae_hidden_bwd": [_p, _p, _int, _p, _i64, _int, _i64, _p, _p, _p, _p, _i64, _p, _p, _p, _int, _p],
+    "yr_cdae_compact_pair": [_p, _p, _i64, _i64, C.c_uint64, _d, _p, _p, _p, _p, _p, _p, _p],
+    "yr_cdae_sampled_decode_splits": [],
+    "yr_cdae_sampled_decode": [_p, _p, _p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p, _p, _p, _p, _p, _p],
     "yr_cdae_hidden_init": [_p, _p, _p, _p, _i64, _int, _i64, _p, _p],
     "yr_dropout": [_p, _p, _d, _i64, _p, _p],
     "yr_sigmoid": [_p, _i64, _p],
@@ -70,7 +73,7 @@ SIGNATURES = {
     "yr_bpr_loss_bwd": [_p, _p, _p, _f, _i64, _p, _p, _p],
     "yr_adam_dense": [_p, _p, _p, _p, _i64, _d, _d, _d, _d, _d, _d, _d, _int, _int, _p],
     "yr_adam_dense_multi": [_p, _p, _p, _p, _p, _int, _d, _d, _d, _d, _d, _d, _d, _int, _int, _p],
-    "yr_adam_dense_flat": [_p, _p, _p, _p, _p, _p, _p, _p, _int, _d, _d, _d, _d, _d, _d, _d, _int, _p],
+    "yr_adam_dense_flat": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _d, _d, _d, _d, _d, _d, _d, _int, _p],
     "yr_csr_rows_to_dense": [_p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _p],
     "yr_negative_mask": [_p, _i64, _i64, _int, C.c_uint64, _p, _p, _p],
     "yr_sgd_dense": [_p, _p, _i64, _d, _d, _int, _p],

@@ -18,7 +18,15 @@ without materialising ``pred`` or the loss gradient w.r.t. it:
     9  Adam / AdamW on all five parameters                                       yr_adam_dense_flat
 
 Eleven launches (8 is a memset and two kernels) against ~26 through autograd, and 5 passes over [B, I]
-data instead of 11.  The gradient buffers belong to the step: dW_h and dV stay all-zero between steps (the
+data instead of 11.
+
+With NS-BCE the loss reads the prediction on the positions where target + negative_mask != 0 only (loss.py:14-16)
+— (1 + neg_times) x the positives of a row, a fraction of a percent of the catalogue — and its gradient w.r.t.
+every other position is exactly zero.  ``decoder="sampled"`` (the default then) replaces 4-6 by one pass over
+those positions: step 1 also lists them (yr_cdae_compact_pair), and yr_cdae_sampled_decode computes, per
+position, the prediction, its BCE term, and its contribution to dz, dW_o and db_o (the 1 / count of the mean is
+applied by the consumers: hidden_bwd to dz, the Adam launch to dW_o / db_o).  Nine launches; the three 2.5 GFLOP
+decoder products are gone.  Validation / evaluation still decode the whole catalogue (models/cdae.py).  The gradient buffers belong to the step: dW_h and dV stay all-zero between steps (the
 Adam launch clears what it read — for dV only the rows the batch touched), dW_o / db_o / db_h are
 overwritten whole.  Results equal the autograd route (models/cdae.py + loss.py + optim.py) up to float
 rounding: the 1 / count factor is applied to the products instead of to G.
@@ -29,21 +37,39 @@ from . import engine
 
 
 class CDAEStep:
-    def __init__(self, model, optimizer, negative_sampling=True):
+    def __init__(self, model, optimizer, negative_sampling=True, decoder="auto"):
+        """``decoder``: "sampled" — forward, loss and the three decoder gradients on the loss positions only
+        (NS-BCE reads nothing else; needs a negative mask), "dense" — the full-catalogue products on the matrix
+        cores, "auto" — sampled when the loss is NS-BCE and the hidden size allows it."""
         from . import optim
         if not isinstance(optimizer, optim.Adam):
             raise NotImplementedError("CDAEStep: optimizer adam or adamw")
         self.model, self.optimizer, self.negative_sampling = model, optimizer, bool(negative_sampling)
         self.params = [model.hidden_layer.weight, model.hidden_layer.bias, model.user_nodes.weight,
                        model.output_layer.weight, model.output_layer.bias]
-        if model.hidden_size % 4:
+        H = model.hidden_size
+        if H % 4:
             raise NotImplementedError("CDAEStep: hidden size must be a multiple of 4")
+        # row marks (gradient rows read / cleared only where the batch touched them) need H / 4 lanes per row to
+        # tile a wave
+        self.row_marks = (H // 4) & (H // 4 - 1) == 0 and H // 4 <= 64
+        can_sample = self.negative_sampling and self.row_marks and H <= 256
+        if decoder == "auto":
+            decoder = "sampled" if can_sample else "dense"
+        if decoder not in ("sampled", "dense") or (decoder == "sampled" and not can_sample):
+            raise NotImplementedError(f"CDAEStep: decoder {decoder!r} with negative_sampling={negative_sampling}, H={H}")
+        self.decoder = decoder
         dev = self.params[0].device
         Wh, bh, V, Wo, bo = (p.data for p in self.params)
         f32 = torch.float32
         self.dWh, self.dV = torch.zeros_like(Wh), torch.zeros_like(V)          # all-zero between steps
-        self.dbh, self.dWo, self.dbo = torch.empty_like(bh), torch.empty_like(Wo), torch.empty_like(bo)
-        self.touched_users = torch.zeros(V.shape[0], dtype=torch.uint8, device=dev)
+        self.dbh = torch.empty_like(bh)
+        if decoder == "sampled":                                                # accumulated into: zero between steps
+            self.dWo, self.dbo = torch.zeros_like(Wo), torch.zeros_like(bo)
+            self.touched_items = torch.zeros(Wo.shape[0], dtype=torch.uint8, device=dev)
+        else:                                                                   # overwritten whole
+            self.dWo, self.dbo = torch.empty_like(Wo), torch.empty_like(bo)
+        self.touched_users = torch.zeros(V.shape[0], dtype=torch.uint8, device=dev) if self.row_marks else None
         self.stats = torch.zeros(2, dtype=f32, device=dev)
         self.loss_accum = torch.zeros(1, dtype=torch.float64, device=dev)
         self.flag = engine.new_error_flag(dev)
@@ -69,15 +95,21 @@ class CDAEStep:
             H, I = Wh.shape
             dev, f32 = Wh.device, torch.float32
             self.z = torch.empty(B, H, dtype=f32, device=dev)
-            ldg = (I + 3) // 4 * 4                                                # 16-byte rows: the gradient products
-            self.G = torch.empty(B, ldg, dtype=f32, device=dev)[:, :I]           # that read G take the tiled kernel
             blob = torch.zeros(B * H + engine.COUNT_WORDS, dtype=f32, device=dev)   # dz and the (spread) position
             self._blob = blob                                                   # counter: one memset clears both
             self.dz = blob[:B * H].view(B, H)
             self.count = blob[B * H:].view(torch.int32)
-            self.n_partials = engine.cdae_decode_loss_partials(B, I)
-            self.partials = torch.empty(self.n_partials, dtype=f32, device=dev)
             self.row_count = torch.empty(B * engine.SPARSE_PARTS, dtype=torch.int32, device=dev)
+            if self.decoder == "sampled":
+                n = B * engine.SPARSE_PARTS * engine.sparse_part_columns(I)
+                self.loss_lists = (torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=f32, device=dev),
+                                   torch.empty(B * engine.SPARSE_PARTS, dtype=torch.int32, device=dev))
+                self.n_partials = B * engine.cdae_sampled_decode_splits()
+            else:
+                ldg = (I + 3) // 4 * 4                                            # 16-byte rows: the gradient products
+                self.G = torch.empty(B, ldg, dtype=f32, device=dev)[:, :I]       # that read G take the tiled kernel
+                self.n_partials = engine.cdae_decode_loss_partials(B, I)
+            self.partials = torch.empty(self.n_partials, dtype=f32, device=dev)
             self._batch = B
 
     @torch.no_grad()
@@ -93,28 +125,43 @@ class CDAEStep:
         self._buffers(B)
         user_id = user_id.contiguous()
         x = x.contiguous()
-        rows = engine.SparseRows(x if x_in is None else x_in.contiguous(), seed if x_in is None else 0,
-                                 p if x_in is None else 0.0, count=self.row_count)
+        neg = None if negative_mask is None else negative_mask.contiguous()
+        sampled = self.decoder == "sampled"
+        if sampled and neg is None:
+            raise engine.EngineError("the sampled decoder needs the negative mask")
+        if sampled and x_in is None:                      # both lists of every row from one pass over x and the mask
+            rows = engine.SparseRows(x, seed, p, count=self.row_count, negative_mask=neg, loss_lists=self.loss_lists)
+        else:
+            if sampled:                                   # loss positions of (x, mask); the encoder lists follow
+                engine.SparseRows(x, 0, 0.0, count=self.row_count, negative_mask=neg, loss_lists=self.loss_lists)
+            rows = engine.SparseRows(x if x_in is None else x_in.contiguous(), seed if x_in is None else 0,
+                                     p if x_in is None else 0.0, count=self.row_count)
         engine.cdae_sparse_encode(rows, Wh, bh, V, user_id, model._hidden_act, err_flag=self.flag, out=self.z)
         self._blob.zero_()
-        neg = None if negative_mask is None else negative_mask.contiguous()
-        engine.cdae_decode_loss(self.z, Wo, bo, x, neg, model._output_act, self.G, self.partials, self.count)
-        engine.gemm_f32(self.G, self.z, transA=True, out=self.dWo, alpha_count=self.count, rowsum=self.dbo)
-        engine.gemm_f32(self.G, Wo, out=self.dz, accumulate=True, split_k=max(1, min(256, Wo.shape[0] // 256)),
-                        alpha_count=self.count)
+        if sampled:
+            engine.cdae_sampled_decode(self.loss_lists, self.z, Wo, bo, model._output_act, self.dz, self.dWo,
+                                       self.dbo, self.touched_items, self.partials, self.count)
+        else:
+            engine.cdae_decode_loss(self.z, Wo, bo, x, neg, model._output_act, self.G, self.partials, self.count)
+            engine.gemm_f32(self.G, self.z, transA=True, out=self.dWo, alpha_count=self.count, rowsum=self.dbo)
+            engine.gemm_f32(self.G, Wo, out=self.dz, accumulate=True, split_k=max(1, min(256, Wo.shape[0] // 256)),
+                            alpha_count=self.count)
         engine.cdae_hidden_bwd(self.dz, self.z, model._hidden_act, user_id, self.dV, self.touched_users, self.dbh,
-                               self.partials, self.n_partials, self.count, self.stats, self.loss_accum)
+                               self.partials, self.n_partials, self.count, self.stats, self.loss_accum,
+                               scale_dz=sampled)
         engine.cdae_sparse_dwh(rows, self.dz, self.dWh)
         group = self.optimizer.param_groups[0]
         st = [self.optimizer.state[q] for q in self.params]
         t = int(st[0]["step"]) + 1
         grads = (self.dWh, self.dbh, self.dV, self.dWo, self.dbo)
-        marks = (None, None, self.touched_users, None, None)
-        clear = (True, False, False, False, False)
-        engine.adam_dense_flat([(q.data, g, s["exp_avg"], s["exp_avg_sq"], m, c)
-                                for q, g, s, m, c in zip(self.params, grads, st, marks, clear)],
+        marks = (None, None, self.touched_users, self.touched_items if sampled else None, None)
+        clear = (True, False, self.touched_users is None, False, sampled)
+        scaled = (False, False, False, sampled, sampled)
+        engine.adam_dense_flat([(q.data, g, s["exp_avg"], s["exp_avg_sq"], m, c, sc)
+                                for q, g, s, m, c, sc in zip(self.params, grads, st, marks, clear, scaled)],
                                t, group["lr"], group["betas"][0], group["betas"][1], group["eps"],
-                               group["weight_decay"], decoupled=self.optimizer._decoupled)
+                               group["weight_decay"], decoupled=self.optimizer._decoupled,
+                               grad_count=self.count if sampled else None)
         for s in st:
             s["step"] = t
 

@@ -174,19 +174,6 @@ struct TileLoader {
 //                  selected (target + negmask != 0):  (y - t) / max((1 - y) y, 1e-12) * act'(y),  else 0
 //              plus one loss partial per workgroup (fixed summation order) and the number of selected positions
 //              (integer atomic: exact, order-free).  `pred` (may be NULL) receives y.
-// The number of loss positions of a step is an integer sum over all decoder workgroups.  One counter would take
-// ~10 k same-address atomics (measured: +90 us on a 40 us kernel); it is spread over YR_COUNT_SLOTS words, one
-// 128-byte line each, and every reader adds the slots up (one 64-lane gather + wave sum).
-constexpr int kCountStride = YR_COUNT_WORDS / YR_COUNT_SLOTS;
-static_assert(YR_COUNT_SLOTS == kWave, "one slot per lane");
-
-__device__ __forceinline__ int32_t spread_count(const int32_t* __restrict__ count, int lane) {
-  int32_t c = count[lane * kCountStride];
-#pragma unroll
-  for (int d = kWave / 2; d >= 1; d >>= 1) c += __shfl_xor(c, d, kWave);
-  return c;
-}
-
 struct GemmExtra {
   const int32_t* count;
   float* rowsum;
@@ -358,7 +345,7 @@ __global__ __launch_bounds__(kBlock) void gemm_f32_tiled_kernel(const float* __r
     if (threadIdx.x == 0) {
       const int tot = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
       const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
-      if (tot > 0) atomicAdd(ex.count_out + (wg % YR_COUNT_SLOTS) * kCountStride, tot);
+      spread_count_add(ex.count_out, wg, tot);
     }
   }
 }
@@ -559,7 +546,7 @@ __global__ __launch_bounds__(kHiddenBwdBlock) void cdae_hidden_bwd_kernel(
     float* __restrict__ dz, const float* __restrict__ z, int act, const int64_t* __restrict__ user, int64_t B, int H,
     int64_t num_users, float* __restrict__ dV, uint8_t* __restrict__ touched, float* __restrict__ dbh,
     const float* __restrict__ partial_loss, int64_t n_partials, const int32_t* __restrict__ count,
-    float* __restrict__ stats, double* __restrict__ loss_accum, unsigned col_blocks) {
+    float* __restrict__ stats, double* __restrict__ loss_accum, unsigned col_blocks, int scale_dz) {
   __shared__ float s_part[kHiddenBwdWaves][kWave];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   if (blockIdx.x >= col_blocks) {                    // the loss workgroup
@@ -581,6 +568,11 @@ __global__ __launch_bounds__(kHiddenBwdBlock) void cdae_hidden_bwd_kernel(
   }
   const int c = blockIdx.x * kWave + lane;
   float acc = 0.0f;
+  float alpha = 1.0f;
+  if (scale_dz) {                                      // dz arrives without the 1 / count of the mean loss
+    const int32_t n = spread_count(count, lane);
+    alpha = n > 0 ? 1.0f / (float)n : 0.0f;
+  }
   if (c < H) {
     constexpr int U = 8;                               // rows in flight per wave: loads first, then stores / atomics
     for (int64_t r0 = wave; r0 < B; r0 += U * kHiddenBwdWaves) {
@@ -597,6 +589,7 @@ __global__ __launch_bounds__(kHiddenBwdBlock) void cdae_hidden_bwd_kernel(
       for (int q = 0; q < U; ++q) {
         const int64_t r = r0 + (int64_t)q * kHiddenBwdWaves;
         if (r >= B) break;
+        g[q] *= alpha;
         if (act == 1) g[q] *= y[q] * (1.0f - y[q]);
         dz[r * H + c] = g[q];
         acc += g[q];
@@ -724,14 +717,15 @@ extern "C" int yr_cdae_decode_loss(const float* z, const float* Wo, const float*
 extern "C" int yr_cdae_hidden_bwd(float* dz, const float* z, int act, const int64_t* user, int64_t B, int H,
                                   int64_t num_users, float* dV, uint8_t* touched_users, float* dbh,
                                   const float* partial_loss, int64_t n_partials, const int32_t* count, float* stats,
-                                  double* loss_accum, void* stream) {
+                                  double* loss_accum, int scale_dz, void* stream) {
   if (B < 0 || H <= 0 || num_users <= 0 || n_partials < 0 || (act != 0 && act != 1)) return YR_ERR_BADARG;
   if (!dz || !z || !user || !dV || !dbh) return YR_ERR_BADARG;
   if (n_partials > 0 && (!partial_loss || !count || !stats)) return YR_ERR_BADARG;
+  if (scale_dz && !count) return YR_ERR_BADARG;
   const unsigned col_blocks = (unsigned)((H + kWave - 1) / kWave);
   hipLaunchKernelGGL(cdae_hidden_bwd_kernel, dim3(col_blocks + (n_partials > 0 ? 1u : 0u)), dim3(kHiddenBwdBlock), 0,
                      (hipStream_t)stream, dz, z, act, user, B, H, num_users, dV, touched_users, dbh, partial_loss,
-                     n_partials, count, stats, loss_accum, col_blocks);
+                     n_partials, count, stats, loss_accum, col_blocks, scale_dz ? 1 : 0);
   return launch_status();
 }
 

@@ -197,6 +197,177 @@ __global__ __launch_bounds__(kBlock) void cdae_sparse_dwh_scatter_kernel(const i
   }
 }
 
+// ---- the decoder of a TRAINING step on the loss positions only ----
+// NSBCELoss (loss.py:12-16) reads the prediction at the positions where target + negative_mask != 0 and nowhere
+// else: ~(1 + neg_times) x the positives of a row, a fraction of a percent of the catalogue.  The gradient w.r.t.
+// the prediction is exactly zero elsewhere, so the three dense decoder products of a training step
+// (z W_o^T, G^T z, G W_o: 2.5 GFLOP each at full size) reduce to one pass over the position lists.
+//
+// yr_cdae_compact_pair: ONE pass over x and the negative mask makes both lists of a row — the non-zeros of
+//   dropout_p(x) (the encoder's input, as yr_cdae_compact_rows) and the loss positions (column, target).
+__global__ __launch_bounds__(kBlock) void cdae_compact_pair_kernel(
+    const float* __restrict__ x, const float* __restrict__ negmask, int64_t I, uint64_t seed, float p, float scale,
+    int64_t cpp, int32_t* __restrict__ cols, float* __restrict__ vals, int32_t* __restrict__ count,
+    int32_t* __restrict__ lcols, float* __restrict__ lvals, int32_t* __restrict__ lcount) {
+  const int64_t r = blockIdx.x;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int part = blockIdx.y * kWavesPerBlock + wave;
+  const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+  const float* row = x + r * I;
+  const float* nrow = negmask + r * I;
+  const int64_t c_lo = (int64_t)part * cpp, c_hi = min(I, c_lo + cpp);
+  const int64_t at0 = (r * kParts + part) * cpp;
+  int base = 0, lbase = 0;
+  for (int64_t c0 = c_lo; c0 < c_hi; c0 += kWave * 4) {
+    const int64_t c = c0 + lane * 4;
+    float t[4] = {0.f, 0.f, 0.f, 0.f}, m[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (c + k < c_hi) { t[k] = row[c + k]; m[k] = nrow[c + k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = t[k];
+    if (p > 0.0f && (v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (v[k] == 0.f) continue;
+        const int64_t e = r * I + c + k;
+        const uint4 w = cs_philox4x32_10(make_uint4((uint32_t)(e >> 2), (uint32_t)((e >> 2) >> 32), 0u, 0u), key);
+        const uint32_t word = (e & 3) == 0 ? w.x : (e & 3) == 1 ? w.y : (e & 3) == 2 ? w.z : w.w;
+        v[k] = cs_u01(word) >= p ? v[k] * scale : 0.0f;
+      }
+    }
+    bool sel[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sel[k] = t[k] + m[k] != 0.0f;
+    const int mine = (v[0] != 0.f) + (v[1] != 0.f) + (v[2] != 0.f) + (v[3] != 0.f);
+    const int lmine = (int)sel[0] + (int)sel[1] + (int)sel[2] + (int)sel[3];
+    int inc = mine | (lmine << 16);                    // both prefix sums in one scan (each < 2^15 per part)
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int tt = __shfl_up(inc, d, kWave);
+      if (lane >= d) inc += tt;
+    }
+    int at = base + (inc & 0xffff) - mine;
+    int lat = lbase + (inc >> 16) - lmine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (v[k] != 0.f) { cols[at0 + at] = (int32_t)(c + k); vals[at0 + at] = v[k]; ++at; }
+      if (sel[k]) { lcols[at0 + lat] = (int32_t)(c + k); lvals[at0 + lat] = t[k]; ++lat; }
+    }
+    const int tot = __shfl(inc, kWave - 1, kWave);
+    base += tot & 0xffff;
+    lbase += tot >> 16;
+  }
+  if (lane == 0) { count[r * kParts + part] = base; lcount[r * kParts + part] = lbase; }
+}
+
+// yr_cdae_sampled_decode: one workgroup per (row, 1 / S of its position list); a HALF-wave per position: lane l
+//   holds floats [4 l, 4 l + 4) of the W_o row (one 512-byte gather per position at H = 128), the dot with z
+//   is a 32-lane DPP sum; then, with the same W_o row still in registers,
+//     y = act(z . W_o[i] + b_o[i]);  BCE term -> the workgroup's loss partial (fixed order);
+//     g = (y - t) / max((1 - y) y, 1e-12) * act'(y)            (without 1 / count: the consumers scale)
+//     dz[b, :]   += g W_o[i, :]        registers, combined over the half-waves in fixed order
+//     dW_o[i, :] += g z[b, :]          float atomics, 512 contiguous bytes per position; item i marked
+//     db_o[i]    += g
+//   count (spread, see YR_COUNT_SLOTS) += positions.  dW_o / db_o must be zero where no earlier position of
+//   this step wrote; dz zero on entry when S > 1.
+constexpr int kHalf = 32;
+constexpr int kHalves = kBlock / kHalf;
+
+template <int NK>       // H <= 32 * NK: lane l of a half-wave holds floats l, l + 32, ... of a row, so that every
+                        // load / atomic instruction of a half-wave covers 128 contiguous bytes
+__global__ __launch_bounds__(kBlock) void cdae_sampled_decode_kernel(
+    const int32_t* __restrict__ lcols, const float* __restrict__ lvals, const int32_t* __restrict__ lcount,
+    int64_t cpp, const float* __restrict__ z, const float* __restrict__ Wo, const float* __restrict__ bo, int H,
+    int act, int splits, float* __restrict__ dz, float* __restrict__ dWo, float* __restrict__ dbo,
+    uint8_t* __restrict__ touched_items, float* __restrict__ partial_loss, int32_t* __restrict__ count) {
+  __shared__ int s_pre[kParts + 1];
+  __shared__ int32_t s_col[kListCap];
+  __shared__ float s_val[kListCap];
+  __shared__ float s_dz[kHalves][kHalf * NK];
+  __shared__ float s_loss[kHalves];
+  __shared__ int s_done[kHalves];
+  const int64_t r = blockIdx.x;
+  const int split = blockIdx.y;
+  const int lane = threadIdx.x & (kHalf - 1), half = threadIdx.x / kHalf;
+  float zr[NK], acc[NK];
+  bool in[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    in[k] = lane + kHalf * k < H;
+    zr[k] = in[k] ? z[r * H + lane + kHalf * k] : 0.0f;
+    acc[k] = 0.0f;
+  }
+  float loss = 0.0f;
+  int done = 0;
+  for (int skip = 0;; skip += kListCap) {
+    const int n = gather_row_list(lcols, lvals, lcount, cpp, r, skip, s_pre, s_col, s_val);
+    // this workgroup's share of the staged entries: j = split, split + splits, ...; half-wave `half` takes every
+    // kHalves-th of those, two at a time (the second W_o row is in flight while the first is used)
+    for (int j0 = split + half * splits; j0 < n; j0 += 2 * kHalves * splits) {
+      const int j1 = j0 + kHalves * splits;
+      const bool two = j1 < n;
+      const int col0 = s_col[j0], col1 = s_col[two ? j1 : j0];
+      float w0[NK], w1[NK];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int q = min(lane + kHalf * k, H - 1);
+        w0[k] = Wo[(int64_t)col0 * H + q];
+        w1[k] = Wo[(int64_t)col1 * H + q];
+      }
+      const float b0 = bo ? bo[col0] : 0.0f, b1 = bo ? bo[col1] : 0.0f;
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        if (which == 1 && !two) break;
+        const int col = which ? col1 : col0;
+        const float t = s_val[which ? j1 : j0];
+        float d = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) d += in[k] ? (which ? w1[k] : w0[k]) * zr[k] : 0.0f;
+        d = group_sum_dpp<kHalf>(d);
+        float y = d + (which ? b1 : b0);
+        if (act == 1) y = 1.0f / (1.0f + expf(-y));
+        loss -= t * fmaxf(logf(y), -100.0f) + (1.0f - t) * fmaxf(logf(1.0f - y), -100.0f);
+        float g = (y - t) / fmaxf((1.0f - y) * y, 1e-12f);
+        if (act == 1) g *= y * (1.0f - y);
+        ++done;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          acc[k] += g * (which ? w1[k] : w0[k]);
+          if (in[k]) atomicAdd(dWo + (int64_t)col * H + lane + kHalf * k, g * zr[k]);
+        }
+        if (lane == 0) {
+          atomicAdd(dbo + col, g);
+          touched_items[col] = 1;
+        }
+      }
+    }
+    const bool more = skip + n < s_pre[kParts];
+    __syncthreads();
+    if (!more) break;
+  }
+  // combine the half-waves in fixed order
+#pragma unroll
+  for (int k = 0; k < NK; ++k) s_dz[half][lane + kHalf * k] = acc[k];
+  if (lane == 0) { s_loss[half] = loss; s_done[half] = done; }
+  __syncthreads();
+  for (int h = threadIdx.x; h < H; h += kBlock) {
+    float tsum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kHalves; ++k) tsum += s_dz[k][h];
+    if (splits > 1) atomicAdd(dz + r * H + h, tsum);
+    else dz[r * H + h] = tsum;
+  }
+  if (threadIdx.x == 0) {
+    float tl = 0.0f;
+    int tot = 0;
+#pragma unroll
+    for (int k = 0; k < kHalves; ++k) { tl += s_loss[k]; tot += s_done[k]; }
+    partial_loss[r * splits + split] = tl;
+    spread_count_add(count, blockIdx.y * gridDim.x + blockIdx.x, tot);
+  }
+}
+
 }  // namespace yr
 
 using namespace yr;
@@ -243,5 +414,46 @@ extern "C" int yr_cdae_sparse_dwh(const int32_t* cols, const float* vals, const 
                      dz, H, scratch_T, claim, epoch, touched, n_touched);
   hipLaunchKernelGGL(cdae_sparse_dwh_scatter_kernel, dim3(2048), dim3(kBlock), 0, s, touched, n_touched, scratch_T, I,
                      H, dWh);
+  return launch_status();
+}
+
+extern "C" int yr_cdae_compact_pair(const float* x, const float* negative_mask, int64_t B, int64_t I, uint64_t seed,
+                                    double p, int32_t* cols, float* vals, int32_t* count, int32_t* loss_cols,
+                                    float* loss_targets, int32_t* loss_count, void* stream) {
+  if (B < 0 || I <= 0 || p < 0.0 || p >= 1.0) return YR_ERR_BADARG;
+  if (B == 0) return 0;
+  if (!x || !negative_mask || !cols || !vals || !count || !loss_cols || !loss_targets || !loss_count)
+    return YR_ERR_BADARG;
+  const int64_t cpp = yr_cdae_sparse_part_columns(I);
+  if (cpp >= 32768) return YR_ERR_UNSUPPORTED;           // the two prefix sums share one 32-bit scan
+  hipLaunchKernelGGL(cdae_compact_pair_kernel, dim3((unsigned)B, kParts / kWavesPerBlock), dim3(kBlock), 0,
+                     (hipStream_t)stream, x, negative_mask, I, seed, (float)p, (float)(1.0 / (1.0 - p)), cpp, cols,
+                     vals, count, loss_cols, loss_targets, loss_count);
+  return launch_status();
+}
+
+extern "C" int yr_cdae_sampled_decode_splits(void) { return 2; }
+
+extern "C" int yr_cdae_sampled_decode(const int32_t* loss_cols, const float* loss_targets, const int32_t* loss_count,
+                                      const float* z, const float* Wo, const float* bo, int64_t B, int64_t I, int H,
+                                      int act, float* dz, float* dWo, float* dbo, uint8_t* touched_items,
+                                      float* partial_loss, int32_t* count, void* stream) {
+  if (B < 0 || I <= 0 || H <= 0 || (act != 0 && act != 1)) return YR_ERR_BADARG;
+  if (H > 256) return YR_ERR_UNSUPPORTED;
+  if (B == 0) return 0;
+  if (!loss_cols || !loss_targets || !loss_count || !z || !Wo || !dz || !dWo || !dbo || !touched_items ||
+      !partial_loss || !count)
+    return YR_ERR_BADARG;
+  if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(Wo)) & 15) return YR_ERR_BADARG;
+  const int splits = yr_cdae_sampled_decode_splits();
+  const int64_t cpp = yr_cdae_sparse_part_columns(I);
+  const dim3 grid((unsigned)B, (unsigned)splits);
+  hipStream_t s = (hipStream_t)stream;
+  if (H <= 128)
+    hipLaunchKernelGGL((cdae_sampled_decode_kernel<4>), grid, dim3(kBlock), 0, s, loss_cols, loss_targets, loss_count,
+                       cpp, z, Wo, bo, H, act, splits, dz, dWo, dbo, touched_items, partial_loss, count);
+  else
+    hipLaunchKernelGGL((cdae_sampled_decode_kernel<8>), grid, dim3(kBlock), 0, s, loss_cols, loss_targets, loss_count,
+                       cpp, z, Wo, bo, H, act, splits, dz, dWo, dbo, touched_items, partial_loss, count);
   return launch_status();
 }

@@ -151,15 +151,22 @@ struct AdamFlat {
   uint8_t* touched[YR_ADAM_MULTI_MAX];
   int64_t n4[YR_ADAM_MULTI_MAX];
   int64_t chunk_end[YR_ADAM_MULTI_MAX];  // running end of tensor k in chunks
-  int row4[YR_ADAM_MULTI_MAX];
+  int row4[YR_ADAM_MULTI_MAX];           // log2 of the float4 per marked row
   int clear[YR_ADAM_MULTI_MAX];
   int tail[YR_ADAM_MULTI_MAX];           // n % 4
+  int scaled[YR_ADAM_MULTI_MAX];         // gradient is multiplied by 1 / grad_count before use
+  const int32_t* grad_count;             // spread count (YR_COUNT_SLOTS) or NULL
   int count;
 };
 
 template <bool DECOUPLED>
 __global__ __launch_bounds__(kBlock) void adam_flat_kernel(AdamFlat t, AdamScalars c) {
   const int64_t chunks = t.chunk_end[t.count - 1];
+  float inv_count = 1.0f;
+  if (t.grad_count) {
+    const int32_t n = spread_count(t.grad_count, threadIdx.x & (kWave - 1));
+    inv_count = n > 0 ? 1.0f / (float)n : 0.0f;
+  }
   for (int64_t ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
     int k = 0;
     for (int q = 0; q + 1 < t.count; ++q)
@@ -171,8 +178,9 @@ __global__ __launch_bounds__(kBlock) void adam_flat_kernel(AdamFlat t, AdamScala
         float* g = reinterpret_cast<float*>(t.g[k] + j);
         float* m = reinterpret_cast<float*>(t.m[k] + j);
         float* v = reinterpret_cast<float*>(t.v[k] + j);
+        const float gs = t.scaled[k] ? inv_count : 1.0f;
         for (int e = 0; e < t.tail[k]; ++e) {
-          adam_element<DECOUPLED>(p[e], g[e], m[e], v[e], c);
+          adam_element<DECOUPLED>(p[e], g[e] * gs, m[e], v[e], c);
           if (t.clear[k]) g[e] = 0.0f;
         }
       }
@@ -180,16 +188,17 @@ __global__ __launch_bounds__(kBlock) void adam_flat_kernel(AdamFlat t, AdamScala
     }
     float4* gp = t.g[k];
     uint8_t* tp = t.touched[k];
-    const int row4 = t.row4[k];
+    const int shift = t.row4[k];                      // log2(float4 per row)
     float4 P = t.p[k][j], M = t.m[k][j], V = t.v[k][j];
     float4 G = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int64_t row = tp ? j / row4 : 0;
+    const int64_t row = j >> shift;
     const bool has = tp ? tp[row] != 0 : true;
     if (has) {
       G = gp[j];
       if (tp || t.clear[k]) gp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tp && j % row4 == 0) tp[row] = 0;           // after every lane of the row (same wave) has read the mark
+      if (tp && (j & ((1 << shift) - 1)) == 0) tp[row] = 0;   // after every lane of the row (same wave) has read the mark
     }
+    if (t.scaled[k]) { G.x *= inv_count; G.y *= inv_count; G.z *= inv_count; G.w *= inv_count; }
     adam_element<DECOUPLED>(P.x, G.x, M.x, V.x, c);
     adam_element<DECOUPLED>(P.y, G.y, M.y, V.y, c);
     adam_element<DECOUPLED>(P.z, G.z, M.z, V.z, c);
@@ -352,7 +361,7 @@ extern "C" int yr_adam_dense_multi(float* const* p, float* const* g, float* cons
 
 extern "C" int yr_adam_dense_flat(float* const* p, float* const* g, float* const* m, float* const* v,
                                   const int64_t* n, uint8_t* const* touched, const int* row_width, const int* clear,
-                                  int count, double lr, double step_size, double bc2_sqrt, double beta1, double beta2,
+                                  const int* scaled, const int32_t* grad_count, int count, double lr, double step_size, double bc2_sqrt, double beta1, double beta2,
                                   double eps, double weight_decay, int mode, void* stream) {
   if (count < 0 || count > YR_ADAM_MULTI_MAX) return YR_ERR_BADARG;
   if (count == 0) return 0;
@@ -372,8 +381,11 @@ extern "C" int yr_adam_dense_flat(float* const* p, float* const* g, float* const
     if (tp && (rw <= 0 || (rw & 3) || n[k] % rw || rw / 4 > kWave || kWave % (rw / 4))) return YR_ERR_BADARG;
     t.p[used] = (float4*)p[k]; t.g[used] = (float4*)g[k]; t.m[used] = (float4*)m[k]; t.v[used] = (float4*)v[k];
     t.touched[used] = tp;
-    t.row4[used] = tp ? rw / 4 : 1;
+    int lg = 0;
+    while (tp && (1 << lg) < rw / 4) ++lg;
+    t.row4[used] = lg;
     t.clear[used] = clear ? clear[k] : 0;
+    t.scaled[used] = (scaled && grad_count) ? scaled[k] : 0;
     t.n4[used] = n[k] / 4;
     t.tail[used] = (int)(n[k] & 3);
     chunks += (n[k] / 4 + (t.tail[used] ? 1 : 0) + kBlock - 1) / kBlock;   // one more lane for the tail
@@ -382,6 +394,7 @@ extern "C" int yr_adam_dense_flat(float* const* p, float* const* g, float* const
   }
   if (used == 0) return 0;
   t.count = used;
+  t.grad_count = grad_count;
   AdamScalars c;
   c.decay_mul = (float)(1.0 - lr * weight_decay);
   c.neg_step = (float)(-step_size);

@@ -392,10 +392,32 @@ def cdae_decode_loss(z, Wo, bo, target, negative_mask, act, G, partial_loss, cou
     return G
 
 
+def cdae_sampled_decode_splits():
+    return int(_lib.load().yr_cdae_sampled_decode_splits())
+
+
+def cdae_sampled_decode(loss_lists, z, Wo, bo, act, dz, dWo, dbo, touched_items, partial_loss, count):
+    """Decoder forward + loss + all three decoder gradients on the loss positions only (yr_cdae_sampled_decode);
+    everything it adds to comes out WITHOUT the 1 / count of the mean loss."""
+    lib = _lib.load()
+    f32 = torch.float32
+    lc, lv, ln = loss_lists
+    B, H = z.shape
+    I = Wo.shape[0]
+    if partial_loss.numel() < B * cdae_sampled_decode_splits() or count.numel() != COUNT_WORDS:
+        raise EngineError("bad buffers for cdae_sampled_decode")
+    check(lib.yr_cdae_sampled_decode(_dev(lc, torch.int32, "loss_cols"), _dev(lv, f32, "loss_targets"),
+                                     _dev(ln, torch.int32, "loss_count"), _dev(z, f32, "z"), _dev(Wo, f32, "Wo"),
+                                     _opt(bo, f32, "bo"), B, I, H, int(act), _dev(dz, f32, "dz"), _dev(dWo, f32, "dWo"),
+                                     _dev(dbo, f32, "dbo"), _dev(touched_items, torch.uint8, "touched_items"),
+                                     _dev(partial_loss, f32, "partial_loss"), _dev(count, torch.int32, "count"),
+                                     _stream()), "yr_cdae_sampled_decode")
+
+
 def cdae_hidden_bwd(dz, z, act, user, dV, touched_users, dbh, partial_loss=None, n_partials=0, count=None,
-                    stats=None, loss_accum=None):
-    """dz <- dz * act'(z); dbh = column sums; dV[user] += dz (rows marked in ``touched_users``); with
-    ``n_partials`` > 0 also the loss of the step into ``stats`` / ``loss_accum`` (yr_cdae_hidden_bwd)."""
+                    stats=None, loss_accum=None, scale_dz=False):
+    """dz <- dz * act'(z) (``scale_dz``: dz / count first); dbh = column sums; dV[user] += dz (rows marked in
+    ``touched_users``); with ``n_partials`` > 0 also the loss of the step into ``stats`` / ``loss_accum``."""
     lib = _lib.load()
     f32 = torch.float32
     B, H = dz.shape
@@ -403,7 +425,8 @@ def cdae_hidden_bwd(dz, z, act, user, dV, touched_users, dbh, partial_loss=None,
                                  B, H, dV.shape[0], _dev(dV, f32, "dV"), _opt(touched_users, torch.uint8, "touched"),
                                  _dev(dbh, f32, "dbh"), _opt(partial_loss, f32, "partial_loss"), int(n_partials),
                                  _opt(count, torch.int32, "count"), _opt(stats, f32, "stats"),
-                                 _opt(loss_accum, torch.float64, "loss_accum"), _stream()), "yr_cdae_hidden_bwd")
+                                 _opt(loss_accum, torch.float64, "loss_accum"), 1 if scale_dz else 0, _stream()),
+          "yr_cdae_hidden_bwd")
 
 
 def cdae_hidden_init(bias, V, user, err_flag=None):
@@ -428,12 +451,20 @@ def dropout(x, rnd, p):
 SPARSE_PARTS = 32       # csrc/cdae_sparse.hip kParts
 
 
+def sparse_part_columns(I):
+    """Columns per sub-list of a SparseRows row (list buffers hold B * SPARSE_PARTS * this many entries)."""
+    return int(_lib.load().yr_cdae_sparse_part_columns(int(I)))
+
+
 class SparseRows:
     """(column, value) lists of the non-zeros of dropout_p(x), 32 sub-lists per row (csrc/cdae_sparse.hip);
     the list buffers are sized for the worst case once per batch shape and reused by the next call."""
     _pool = {}
 
-    def __init__(self, x, seed=0, p=0.0, count=None):
+    def __init__(self, x, seed=0, p=0.0, count=None, negative_mask=None, loss_lists=None):
+        """``negative_mask`` + ``loss_lists`` (cols int32, targets f32, count int32 buffers like this object's):
+        the same pass also writes the loss positions of every row — target + negative_mask != 0 — as
+        (column, target) lists (yr_cdae_compact_pair)."""
         lib = _lib.load()
         B, I = x.shape
         self.cpp = int(lib.yr_cdae_sparse_part_columns(I))
@@ -446,6 +477,16 @@ class SparseRows:
         self.cols, self.vals = buf
         self.count = torch.empty(B * SPARSE_PARTS, dtype=torch.int32, device=x.device) if count is None else count
         self.B, self.I = B, I
+        if negative_mask is not None:
+            lc, lv, ln = loss_lists
+            if lc.numel() < self.cols.numel() or lv.numel() < self.cols.numel() or ln.numel() < self.count.numel():
+                raise EngineError("loss list buffers too small")
+            check(lib.yr_cdae_compact_pair(_dev(x, torch.float32, "x"), _dev(negative_mask, torch.float32, "negative_mask"),
+                                           B, I, int(seed) & (2**64 - 1), float(p), self.cols.data_ptr(),
+                                           self.vals.data_ptr(), self.count.data_ptr(), _dev(lc, torch.int32, "loss_cols"),
+                                           _dev(lv, torch.float32, "loss_targets"), _dev(ln, torch.int32, "loss_count"),
+                                           _stream()), "yr_cdae_compact_pair")
+            return
         check(lib.yr_cdae_compact_rows(_dev(x, torch.float32, "x"), B, I, int(seed) & (2**64 - 1), float(p),
                                        self.cols.data_ptr(), self.vals.data_ptr(), self.count.data_ptr(), _stream()),
               "yr_cdae_compact_rows")
@@ -804,10 +845,12 @@ def adam_dense_multi(tensors, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight
                                       1 if zero_grad else 0, _stream()), "yr_adam_dense_multi")
 
 
-def adam_dense_flat(tensors, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, decoupled=False):
+def adam_dense_flat(tensors, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, decoupled=False,
+                    grad_count=None):
     """One launch, 16 bytes per lane, for up to ADAM_MULTI_MAX tensors of any size (yr_adam_dense_flat).
-    ``tensors``: (p, g, m, v, touched, clear) — ``touched`` a uint8 mark per row of p (or None), ``clear`` whether
-    the gradient is zeroed after it is read."""
+    ``tensors``: (p, g, m, v, touched, clear[, scaled]) — ``touched`` a uint8 mark per row of p (or None),
+    ``clear`` whether the gradient is zeroed after it is read, ``scaled`` whether it is first multiplied by
+    1 / ``grad_count`` (a spread int32 count on the device)."""
     import ctypes
     lib = _lib.load()
     if len(tensors) > ADAM_MULTI_MAX:
@@ -823,7 +866,11 @@ def adam_dense_flat(tensors, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_
     marks = (ctypes.c_void_p * n)(*[_opt(t[4], torch.uint8, "touched") for t in tensors])
     widths = (ctypes.c_int * n)(*[int(t[0].shape[-1]) if t[4] is not None else 0 for t in tensors])
     clear = (ctypes.c_int * n)(*[1 if t[5] else 0 for t in tensors])
-    check(lib.yr_adam_dense_flat(cols[0], cols[1], cols[2], cols[3], counts, marks, widths, clear, n, float(lr),
+    scaled = (ctypes.c_int * n)(*[1 if len(t) > 6 and t[6] else 0 for t in tensors])
+    if grad_count is not None and grad_count.numel() != COUNT_WORDS:
+        raise EngineError(f"grad_count: a spread count of {COUNT_WORDS} int32 words")
+    check(lib.yr_adam_dense_flat(cols[0], cols[1], cols[2], cols[3], counts, marks, widths, clear, scaled,
+                                 _opt(grad_count, torch.int32, "grad_count"), n, float(lr),
                                  float(step_size), float(bc2_sqrt), float(beta1), float(beta2), float(eps),
                                  float(weight_decay), OPT_ADAMW if decoupled else OPT_ADAM, _stream()),
           "yr_adam_dense_flat")

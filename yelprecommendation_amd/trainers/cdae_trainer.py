@@ -56,7 +56,8 @@ class CDAETrainer(BaseTrainer):
         if self.model.hidden_size % 4:                     # 16-byte rows for the matrix-core operands
             return None
         if self._step is None or not self._step.bound_to(self.model, self.optimizer):
-            self._step = CDAEStep(self.model, self.optimizer, self.cfg.negative_sampling)
+            self._step = CDAEStep(self.model, self.optimizer, self.cfg.negative_sampling,
+                                  decoder=self.cfg.get("train_decoder", "auto"))
         return self._step
 
     def train(self, train_dataloader) -> float:
