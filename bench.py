@@ -128,32 +128,61 @@ def other_workload(args):
                              "avg_kernel_us": round(t_spmm * 1e6, 2),
                              "gathered_GBps": round(graph.nnz * DIM * 4 / t_spmm / 1e9, 1)})
     else:
+        from yelprecommendation_amd.cdae_step import CDAEStep
         from yelprecommendation_amd.loss import NSBCELoss
         from yelprecommendation_amd.models.cdae import CDAE
         from yelprecommendation_amd.optim import Adam
         from yelprecommendation_amd.utils import make_config
         B, H = 256, 128
-        model = CDAE(make_config("CDAE", hidden_size=H, device="cuda", model_dir="/tmp/yr_bench", lr=1e-4), NI, NU)
-        opt, lossf = Adam(model.parameters(), lr=1e-4), NSBCELoss()
+        cfg = make_config("CDAE", hidden_size=H, device="cuda", model_dir="/tmp/yr_bench", lr=1e-4)
         users = torch.randperm(NU, device=dev)[:B]
-        x = (torch.rand(B, NI, device=dev) < 0.0008).float()
-        neg = (torch.rand(B, NI, device=dev) < 0.004).float() * (1 - x)
-        model.train()
+        x = (torch.rand(B, NI, device=dev) < 0.0008).float()                 # ~30 positives per user
+        neg = (torch.rand(B, NI, device=dev) < 0.004).float() * (1 - x)      # neg_times = 5 (train_config.yaml:33)
+        forms = {}
+        for form in ("sampled", "dense", "autograd"):
+            # the trainer's step (cdae_step.py: NS-BCE -> decoder on the loss positions), the same with the
+            # full-catalogue decoder on the matrix cores, and the launch-by-launch autograd route
+            model = CDAE(cfg, NI, NU)
+            model.train()
+            opt = Adam(model.parameters(), lr=1e-4)
+            if form == "autograd":
+                lossf = NSBCELoss()
 
-        def step():
-            pred = model(users, x)
-            opt.zero_grad(); lossf(pred, x, neg).backward(); opt.step()
-        dt = timed(step)
+                def step():
+                    pred = model(users, x)
+                    opt.zero_grad(); lossf(pred, x, neg).backward(); opt.step()
+            else:
+                fused, k = CDAEStep(model, opt, True, decoder=form), [0]
+
+                def step():
+                    k[0] += 1
+                    fused.step(users, x, neg, seed=k[0], p=model.corruption_level)
+            forms[form] = timed(step)
+            del model, opt
+        dt = forms["sampled"]
+        # dominant kernel of the step: the dense Adam pass over all five parameters (7 x 4 bytes per element)
+        model = CDAE(cfg, NI, NU)
+        tensors = [(p.data, torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p), None, 0)
+                   for p in model.parameters()]
+        t_adam = timed(lambda: engine.adam_dense_flat(tensors, 1, 1e-4))
+        adam_bytes = 28 * sum(p.numel() for p in model.parameters())
         z = torch.rand(B, H, device=dev)
         Wo, bo = model.output_layer.weight.detach(), model.output_layer.bias.detach()
         t_dec = timed(lambda: engine.gemm_f32(z, Wo, transB=True, bias=bo, act=1))
         flops = 2.0 * B * NI * H
         out.update(metric="CDAE full-catalogue train step @ hidden128 batch256", value=round(dt * 1e3, 4),
-                   ms_per_step=round(dt * 1e3, 4), config={"workload": "CDAE H=128, 38,048 items, batch 256, NS-BCE, Adam"},
-                   roofline={"bound": "mfma", "kernel": "gemm_f32_tiled_kernel (decoder z W_o^T + b, sigmoid)",
-                             "achieved": round(flops / t_dec / 1e12, 1), "peak": 157.3, "unit": "TFLOP/s",
-                             "frac": round(flops / t_dec / 1e12 / 157.3, 4), "traffic": None,
-                             "avg_kernel_us": round(t_dec * 1e6, 2)})
+                   ms_per_step=round(dt * 1e3, 4),
+                   config={"workload": "CDAE H=128, 38,048 items, batch 256, NS-BCE (neg_times 5), Adam",
+                           "step": "cdae_step.CDAEStep, decoder on the loss positions"},
+                   step_forms_ms={k: round(v * 1e3, 4) for k, v in forms.items()},
+                   roofline={"bound": "hbm", "kernel": "adam_flat_kernel (all five parameters, one launch)",
+                             "achieved": round(adam_bytes / t_adam / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(adam_bytes / t_adam / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                             "avg_kernel_us": round(t_adam * 1e6, 2),
+                             "eval_decoder": {"bound": "mfma", "kernel": "gemm_f32_tiled_kernel (z W_o^T + b, sigmoid)",
+                                              "achieved": round(flops / t_dec / 1e12, 1), "peak": 157.3,
+                                              "unit": "TFLOP/s", "frac": round(flops / t_dec / 1e12 / 157.3, 4),
+                                              "avg_kernel_us": round(t_dec * 1e6, 2)}})
     print(json.dumps(out), flush=True)
 
 

@@ -319,7 +319,7 @@ int yr_cdae_hidden_bwd(float *dz, const float *z, int act, const int64_t *user, 
  * yr_cdae_sampled_decode: per position (b, i): y = act(z[b] . W_o[i] + b_o[i]), its BCE term (clamped at -100)
  *   into partial_loss[b * yr_cdae_sampled_decode_splits() + s] (fixed order), g = (y - t) / max((1 - y) y,
  *   1e-12) * act'(y), then dz[b,:] += g W_o[i,:] (dz zero on entry), dW_o[i,:] += g z[b,:], db_o[i] += g
- *   (float atomics; both buffers zero on entry where untouched), touched_items[i] = 1, count (spread,
+ *   (float atomics; both buffers zero on entry), count (spread,
  *   YR_COUNT_WORDS, zero on entry) += positions.  Nothing carries the 1 / count of the mean: the consumers apply
  *   it (yr_cdae_hidden_bwd scale_dz = 1, yr_adam_dense_flat scaled[k] = 1).  H a multiple of 4, <= 256. */
 int yr_cdae_compact_pair(const float *x, const float *negative_mask, int64_t B, int64_t I, uint64_t seed,
@@ -328,8 +328,8 @@ int yr_cdae_compact_pair(const float *x, const float *negative_mask, int64_t B, 
 int yr_cdae_sampled_decode_splits(void);
 int yr_cdae_sampled_decode(const int32_t *loss_cols, const float *loss_targets, const int32_t *loss_count,
                            const float *z, const float *Wo, const float *bo, int64_t B, int64_t I, int H,
-                           int act, float *dz, float *dWo, float *dbo, uint8_t *touched_items,
-                           float *partial_loss, int32_t *count, void *stream);
+                           int act, float *dz, float *dWo, float *dbo, float *partial_loss,
+                           int32_t *count, void *stream);
 int yr_cdae_hidden_init(float *zpre, const float *bias, const float *V, const int64_t *user,
                         int64_t B, int H, int64_t num_users, int32_t *err_flag, void *stream);
 int yr_dropout(const float *x, const float *rnd, double p, int64_t n, float *out, void *stream);
@@ -456,7 +456,7 @@ int yr_adam_dense_multi(float *const *p, float *const *g, float *const *m, float
  * (every buffer 16-byte aligned).  touched[k] (HOST array of device pointers,
  * entries may be NULL): one byte per row of row_width[k] floats (row_width / 4 a power of two <= 64) — the
  * gradient of a row is read, cleared and unmarked only where the mark is set (every row is still updated, with
- * grad = 0 elsewhere).  clear[k] != 0: the gradient is cleared after it is read.  scaled[k] != 0 (with
+ * grad = 0 elsewhere).  clear[k] = 1: the gradient is cleared after it is read; 2: only where it is non-zero.  scaled[k] != 0 (with
  * grad_count, a spread count, see YR_COUNT_SLOTS): the gradient is multiplied by 1 / count first. */
 int yr_adam_dense_flat(float *const *p, float *const *g, float *const *m, float *const *v,
                        const int64_t *n, uint8_t *const *touched, const int *row_width, const int *clear,

@@ -66,7 +66,6 @@ class CDAEStep:
         self.dbh = torch.empty_like(bh)
         if decoder == "sampled":                                                # accumulated into: zero between steps
             self.dWo, self.dbo = torch.zeros_like(Wo), torch.zeros_like(bo)
-            self.touched_items = torch.zeros(Wo.shape[0], dtype=torch.uint8, device=dev)
         else:                                                                   # overwritten whole
             self.dWo, self.dbo = torch.empty_like(Wo), torch.empty_like(bo)
         self.touched_users = torch.zeros(V.shape[0], dtype=torch.uint8, device=dev) if self.row_marks else None
@@ -140,7 +139,7 @@ class CDAEStep:
         self._blob.zero_()
         if sampled:
             engine.cdae_sampled_decode(self.loss_lists, self.z, Wo, bo, model._output_act, self.dz, self.dWo,
-                                       self.dbo, self.touched_items, self.partials, self.count)
+                                       self.dbo, self.partials, self.count)
         else:
             engine.cdae_decode_loss(self.z, Wo, bo, x, neg, model._output_act, self.G, self.partials, self.count)
             engine.gemm_f32(self.G, self.z, transA=True, out=self.dWo, alpha_count=self.count, rowsum=self.dbo)
@@ -154,8 +153,8 @@ class CDAEStep:
         st = [self.optimizer.state[q] for q in self.params]
         t = int(st[0]["step"]) + 1
         grads = (self.dWh, self.dbh, self.dV, self.dWo, self.dbo)
-        marks = (None, None, self.touched_users, self.touched_items if sampled else None, None)
-        clear = (True, False, self.touched_users is None, False, sampled)
+        marks = (None, None, self.touched_users, None, None)
+        clear = (1, 0, int(self.touched_users is None), 2 if sampled else 0, int(sampled))
         scaled = (False, False, False, sampled, sampled)
         engine.adam_dense_flat([(q.data, g, s["exp_avg"], s["exp_avg_sq"], m, c, sc)
                                 for q, g, s, m, c, sc in zip(self.params, grads, st, marks, clear, scaled)],

@@ -37,25 +37,47 @@ __device__ __forceinline__ float cs_u01(uint32_t x) { return (float)(x >> 8) * (
 // Philox(counter = flat index / 4) for flat index 4 * (flat / 4) + k.
 constexpr int kParts = 32;
 
-__global__ __launch_bounds__(kBlock) void cdae_compact_rows_kernel(const float* __restrict__ x, int64_t I,
-                                                                   uint64_t seed, float p, float scale, int64_t cpp,
-                                                                   int32_t* __restrict__ cols, float* __restrict__ vals,
-                                                                   int32_t* __restrict__ count) {
+// PAIR: the same pass also lists the LOSS positions of the row, target + negative_mask != 0, as (column, target)
+// (see the sampled decoder below).  The next 1 KB of the row(s) is fetched while the current one is scanned.
+template <bool PAIR>
+__global__ __launch_bounds__(kBlock) void cdae_compact_rows_kernel(
+    const float* __restrict__ x, const float* __restrict__ negmask, int64_t I, uint64_t seed, float p, float scale,
+    int64_t cpp, int32_t* __restrict__ cols, float* __restrict__ vals, int32_t* __restrict__ count,
+    int32_t* __restrict__ lcols, float* __restrict__ lvals, int32_t* __restrict__ lcount) {
   const int64_t r = blockIdx.x;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int part = blockIdx.y * kWavesPerBlock + wave;
   const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
   const float* row = x + r * I;
+  const float* nrow = PAIR ? negmask + r * I : nullptr;
   const int64_t c_lo = (int64_t)part * cpp, c_hi = min(I, c_lo + cpp);
-  int32_t* oc = cols + (r * kParts + part) * cpp;
-  float* ov = vals + (r * kParts + part) * cpp;
-  int base = 0;
+  const int64_t at0 = (r * kParts + part) * cpp;
+  const bool vec = (I & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | (PAIR ? reinterpret_cast<uintptr_t>(negmask) : 0)) & 15) == 0;
+  auto fetch = [&](int64_t c, float (&t)[4], float (&m)[4]) {
+    if (vec && c + 3 < c_hi) {
+      const float4 a = *reinterpret_cast<const float4*>(row + c);
+      t[0] = a.x; t[1] = a.y; t[2] = a.z; t[3] = a.w;
+      if (PAIR) {
+        const float4 b = *reinterpret_cast<const float4*>(nrow + c);
+        m[0] = b.x; m[1] = b.y; m[2] = b.z; m[3] = b.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        t[k] = c + k < c_hi ? row[c + k] : 0.0f;
+        if (PAIR) m[k] = c + k < c_hi ? nrow[c + k] : 0.0f;
+      }
+    }
+  };
+  float tn[4], mn[4] = {0.f, 0.f, 0.f, 0.f};
+  fetch(c_lo + lane * 4, tn, mn);
+  int base = 0, lbase = 0;
   for (int64_t c0 = c_lo; c0 < c_hi; c0 += kWave * 4) {
     const int64_t c = c0 + lane * 4;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    float t[4], m[4], v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (c + k < c_hi) v[k] = row[c + k];
+    for (int k = 0; k < 4; ++k) { t[k] = tn[k]; m[k] = mn[k]; v[k] = tn[k]; }
+    if (c0 + kWave * 4 < c_hi) fetch(c + kWave * 4, tn, mn);
     if (p > 0.0f && (v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f)) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -66,20 +88,32 @@ __global__ __launch_bounds__(kBlock) void cdae_compact_rows_kernel(const float* 
         v[k] = cs_u01(word) >= p ? v[k] * scale : 0.0f;
       }
     }
+    bool sel[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sel[k] = PAIR && t[k] + m[k] != 0.0f;
     const int mine = (v[0] != 0.f) + (v[1] != 0.f) + (v[2] != 0.f) + (v[3] != 0.f);
-    int inc = mine;
+    const int lmine = (int)sel[0] + (int)sel[1] + (int)sel[2] + (int)sel[3];
+    int inc = mine | (lmine << 16);                    // PAIR: both prefix sums in one scan (each < 2^15 per part)
 #pragma unroll
     for (int d = 1; d < kWave; d <<= 1) {
-      const int t = __shfl_up(inc, d, kWave);
-      if (lane >= d) inc += t;
+      const int tt = __shfl_up(inc, d, kWave);
+      if (lane >= d) inc += tt;
     }
-    int at = base + inc - mine;
+    int at = base + (PAIR ? inc & 0xffff : inc) - mine;
+    int lat = lbase + (inc >> 16) - lmine;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (v[k] != 0.f) { oc[at] = (int32_t)(c + k); ov[at] = v[k]; ++at; }
-    base += __shfl(inc, kWave - 1, kWave);
+    for (int k = 0; k < 4; ++k) {
+      if (v[k] != 0.f) { cols[at0 + at] = (int32_t)(c + k); vals[at0 + at] = v[k]; ++at; }
+      if (PAIR && sel[k]) { lcols[at0 + lat] = (int32_t)(c + k); lvals[at0 + lat] = t[k]; ++lat; }
+    }
+    const int tot = __shfl(inc, kWave - 1, kWave);
+    base += PAIR ? tot & 0xffff : tot;
+    lbase += tot >> 16;
   }
-  if (lane == 0) count[r * kParts + part] = base;
+  if (lane == 0) {
+    count[r * kParts + part] = base;
+    if (PAIR) lcount[r * kParts + part] = lbase;
+  }
 }
 
 // The (column, value) list of one row, gathered from its kParts sub-lists into LDS in column order, kListCap
@@ -204,70 +238,15 @@ __global__ __launch_bounds__(kBlock) void cdae_sparse_dwh_scatter_kernel(const i
 // (z W_o^T, G^T z, G W_o: 2.5 GFLOP each at full size) reduce to one pass over the position lists.
 //
 // yr_cdae_compact_pair: ONE pass over x and the negative mask makes both lists of a row — the non-zeros of
-//   dropout_p(x) (the encoder's input, as yr_cdae_compact_rows) and the loss positions (column, target).
-__global__ __launch_bounds__(kBlock) void cdae_compact_pair_kernel(
-    const float* __restrict__ x, const float* __restrict__ negmask, int64_t I, uint64_t seed, float p, float scale,
-    int64_t cpp, int32_t* __restrict__ cols, float* __restrict__ vals, int32_t* __restrict__ count,
-    int32_t* __restrict__ lcols, float* __restrict__ lvals, int32_t* __restrict__ lcount) {
-  const int64_t r = blockIdx.x;
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  const int part = blockIdx.y * kWavesPerBlock + wave;
-  const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
-  const float* row = x + r * I;
-  const float* nrow = negmask + r * I;
-  const int64_t c_lo = (int64_t)part * cpp, c_hi = min(I, c_lo + cpp);
-  const int64_t at0 = (r * kParts + part) * cpp;
-  int base = 0, lbase = 0;
-  for (int64_t c0 = c_lo; c0 < c_hi; c0 += kWave * 4) {
-    const int64_t c = c0 + lane * 4;
-    float t[4] = {0.f, 0.f, 0.f, 0.f}, m[4] = {0.f, 0.f, 0.f, 0.f}, v[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (c + k < c_hi) { t[k] = row[c + k]; m[k] = nrow[c + k]; }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = t[k];
-    if (p > 0.0f && (v[0] != 0.f || v[1] != 0.f || v[2] != 0.f || v[3] != 0.f)) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (v[k] == 0.f) continue;
-        const int64_t e = r * I + c + k;
-        const uint4 w = cs_philox4x32_10(make_uint4((uint32_t)(e >> 2), (uint32_t)((e >> 2) >> 32), 0u, 0u), key);
-        const uint32_t word = (e & 3) == 0 ? w.x : (e & 3) == 1 ? w.y : (e & 3) == 2 ? w.z : w.w;
-        v[k] = cs_u01(word) >= p ? v[k] * scale : 0.0f;
-      }
-    }
-    bool sel[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) sel[k] = t[k] + m[k] != 0.0f;
-    const int mine = (v[0] != 0.f) + (v[1] != 0.f) + (v[2] != 0.f) + (v[3] != 0.f);
-    const int lmine = (int)sel[0] + (int)sel[1] + (int)sel[2] + (int)sel[3];
-    int inc = mine | (lmine << 16);                    // both prefix sums in one scan (each < 2^15 per part)
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-      const int tt = __shfl_up(inc, d, kWave);
-      if (lane >= d) inc += tt;
-    }
-    int at = base + (inc & 0xffff) - mine;
-    int lat = lbase + (inc >> 16) - lmine;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (v[k] != 0.f) { cols[at0 + at] = (int32_t)(c + k); vals[at0 + at] = v[k]; ++at; }
-      if (sel[k]) { lcols[at0 + lat] = (int32_t)(c + k); lvals[at0 + lat] = t[k]; ++lat; }
-    }
-    const int tot = __shfl(inc, kWave - 1, kWave);
-    base += tot & 0xffff;
-    lbase += tot >> 16;
-  }
-  if (lane == 0) { count[r * kParts + part] = base; lcount[r * kParts + part] = lbase; }
-}
-
+//   dropout_p(x) (the encoder's input, as yr_cdae_compact_rows) and the loss positions (column, target):
+//   cdae_compact_rows_kernel<true> above.
 // yr_cdae_sampled_decode: one workgroup per (row, 1 / S of its position list); a HALF-wave per position: lane l
 //   holds floats [4 l, 4 l + 4) of the W_o row (one 512-byte gather per position at H = 128), the dot with z
 //   is a 32-lane DPP sum; then, with the same W_o row still in registers,
 //     y = act(z . W_o[i] + b_o[i]);  BCE term -> the workgroup's loss partial (fixed order);
 //     g = (y - t) / max((1 - y) y, 1e-12) * act'(y)            (without 1 / count: the consumers scale)
 //     dz[b, :]   += g W_o[i, :]        registers, combined over the half-waves in fixed order
-//     dW_o[i, :] += g z[b, :]          float atomics, 512 contiguous bytes per position; item i marked
+//     dW_o[i, :] += g z[b, :]          float atomics, 512 contiguous bytes per position
 //     db_o[i]    += g
 //   count (spread, see YR_COUNT_SLOTS) += positions.  dW_o / db_o must be zero where no earlier position of
 //   this step wrote; dz zero on entry when S > 1.
@@ -280,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void cdae_sampled_decode_kernel(
     const int32_t* __restrict__ lcols, const float* __restrict__ lvals, const int32_t* __restrict__ lcount,
     int64_t cpp, const float* __restrict__ z, const float* __restrict__ Wo, const float* __restrict__ bo, int H,
     int act, int splits, float* __restrict__ dz, float* __restrict__ dWo, float* __restrict__ dbo,
-    uint8_t* __restrict__ touched_items, float* __restrict__ partial_loss, int32_t* __restrict__ count) {
+    float* __restrict__ partial_loss, int32_t* __restrict__ count) {
   __shared__ int s_pre[kParts + 1];
   __shared__ int32_t s_col[kListCap];
   __shared__ float s_val[kListCap];
@@ -336,10 +315,7 @@ __global__ __launch_bounds__(kBlock) void cdae_sampled_decode_kernel(
           acc[k] += g * (which ? w1[k] : w0[k]);
           if (in[k]) atomicAdd(dWo + (int64_t)col * H + lane + kHalf * k, g * zr[k]);
         }
-        if (lane == 0) {
-          atomicAdd(dbo + col, g);
-          touched_items[col] = 1;
-        }
+        if (lane == 0) atomicAdd(dbo + col, g);
       }
     }
     const bool more = skip + n < s_pre[kParts];
@@ -383,9 +359,10 @@ extern "C" int yr_cdae_compact_rows(const float* x, int64_t B, int64_t I, uint64
   if (B < 0 || I <= 0 || p < 0.0 || p >= 1.0) return YR_ERR_BADARG;
   if (B == 0) return 0;
   if (!x || !cols || !vals || !count) return YR_ERR_BADARG;
-  hipLaunchKernelGGL(cdae_compact_rows_kernel, dim3((unsigned)B, kParts / kWavesPerBlock), dim3(kBlock), 0,
-                     (hipStream_t)stream, x, I, seed, (float)p, (float)(1.0 / (1.0 - p)),
-                     yr_cdae_sparse_part_columns(I), cols, vals, count);
+  const int64_t cpp = yr_cdae_sparse_part_columns(I);
+  hipLaunchKernelGGL((cdae_compact_rows_kernel<false>), dim3((unsigned)B, kParts / kWavesPerBlock), dim3(kBlock), 0,
+                     (hipStream_t)stream, x, (const float*)nullptr, I, seed, (float)p, (float)(1.0 / (1.0 - p)), cpp,
+                     cols, vals, count, (int32_t*)nullptr, (float*)nullptr, (int32_t*)nullptr);
   return launch_status();
 }
 
@@ -426,7 +403,7 @@ extern "C" int yr_cdae_compact_pair(const float* x, const float* negative_mask, 
     return YR_ERR_BADARG;
   const int64_t cpp = yr_cdae_sparse_part_columns(I);
   if (cpp >= 32768) return YR_ERR_UNSUPPORTED;           // the two prefix sums share one 32-bit scan
-  hipLaunchKernelGGL(cdae_compact_pair_kernel, dim3((unsigned)B, kParts / kWavesPerBlock), dim3(kBlock), 0,
+  hipLaunchKernelGGL((cdae_compact_rows_kernel<true>), dim3((unsigned)B, kParts / kWavesPerBlock), dim3(kBlock), 0,
                      (hipStream_t)stream, x, negative_mask, I, seed, (float)p, (float)(1.0 / (1.0 - p)), cpp, cols,
                      vals, count, loss_cols, loss_targets, loss_count);
   return launch_status();
@@ -436,13 +413,12 @@ extern "C" int yr_cdae_sampled_decode_splits(void) { return 2; }
 
 extern "C" int yr_cdae_sampled_decode(const int32_t* loss_cols, const float* loss_targets, const int32_t* loss_count,
                                       const float* z, const float* Wo, const float* bo, int64_t B, int64_t I, int H,
-                                      int act, float* dz, float* dWo, float* dbo, uint8_t* touched_items,
-                                      float* partial_loss, int32_t* count, void* stream) {
+                                      int act, float* dz, float* dWo, float* dbo, float* partial_loss,
+                                      int32_t* count, void* stream) {
   if (B < 0 || I <= 0 || H <= 0 || (act != 0 && act != 1)) return YR_ERR_BADARG;
   if (H > 256) return YR_ERR_UNSUPPORTED;
   if (B == 0) return 0;
-  if (!loss_cols || !loss_targets || !loss_count || !z || !Wo || !dz || !dWo || !dbo || !touched_items ||
-      !partial_loss || !count)
+  if (!loss_cols || !loss_targets || !loss_count || !z || !Wo || !dz || !dWo || !dbo || !partial_loss || !count)
     return YR_ERR_BADARG;
   if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(Wo)) & 15) return YR_ERR_BADARG;
   const int splits = yr_cdae_sampled_decode_splits();
@@ -451,9 +427,9 @@ extern "C" int yr_cdae_sampled_decode(const int32_t* loss_cols, const float* los
   hipStream_t s = (hipStream_t)stream;
   if (H <= 128)
     hipLaunchKernelGGL((cdae_sampled_decode_kernel<4>), grid, dim3(kBlock), 0, s, loss_cols, loss_targets, loss_count,
-                       cpp, z, Wo, bo, H, act, splits, dz, dWo, dbo, touched_items, partial_loss, count);
+                       cpp, z, Wo, bo, H, act, splits, dz, dWo, dbo, partial_loss, count);
   else
     hipLaunchKernelGGL((cdae_sampled_decode_kernel<8>), grid, dim3(kBlock), 0, s, loss_cols, loss_targets, loss_count,
-                       cpp, z, Wo, bo, H, act, splits, dz, dWo, dbo, touched_items, partial_loss, count);
+                       cpp, z, Wo, bo, H, act, splits, dz, dWo, dbo, partial_loss, count);
   return launch_status();
 }

@@ -142,7 +142,9 @@ __global__ __launch_bounds__(kBlock) void adam_dual_kernel(DualAdam t, AdamScala
 //   touched[k] != NULL  one byte per row of row4[k] float4: the gradient of a row is read — and cleared, with
 //                       its mark — only where the step touched it (dense Adam semantics: every row is updated,
 //                       with grad = 0 where nothing arrived); the gradient buffer stays all-zero between steps;
-//   clear[k] != 0       the gradient is cleared after it is read (a buffer the next step accumulates into).
+//   clear[k]            1: the gradient is cleared after it is read (a buffer the next step accumulates into);
+//                       2: only where it is non-zero (a mostly-zero buffer: no marks to load first, and the
+//                       lines that hold nothing are not written).
 struct AdamFlat {
   float4* p[YR_ADAM_MULTI_MAX];
   float4* g[YR_ADAM_MULTI_MAX];
@@ -195,7 +197,9 @@ __global__ __launch_bounds__(kBlock) void adam_flat_kernel(AdamFlat t, AdamScala
     const bool has = tp ? tp[row] != 0 : true;
     if (has) {
       G = gp[j];
-      if (tp || t.clear[k]) gp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int clr = t.clear[k];
+      if (tp || clr == 1 || (clr == 2 && (G.x != 0.f || G.y != 0.f || G.z != 0.f || G.w != 0.f)))
+        gp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (tp && (j & ((1 << shift) - 1)) == 0) tp[row] = 0;   // after every lane of the row (same wave) has read the mark
     }
     if (t.scaled[k]) { G.x *= inv_count; G.y *= inv_count; G.z *= inv_count; G.w *= inv_count; }

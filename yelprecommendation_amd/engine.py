@@ -396,7 +396,7 @@ def cdae_sampled_decode_splits():
     return int(_lib.load().yr_cdae_sampled_decode_splits())
 
 
-def cdae_sampled_decode(loss_lists, z, Wo, bo, act, dz, dWo, dbo, touched_items, partial_loss, count):
+def cdae_sampled_decode(loss_lists, z, Wo, bo, act, dz, dWo, dbo, partial_loss, count):
     """Decoder forward + loss + all three decoder gradients on the loss positions only (yr_cdae_sampled_decode);
     everything it adds to comes out WITHOUT the 1 / count of the mean loss."""
     lib = _lib.load()
@@ -409,8 +409,7 @@ def cdae_sampled_decode(loss_lists, z, Wo, bo, act, dz, dWo, dbo, touched_items,
     check(lib.yr_cdae_sampled_decode(_dev(lc, torch.int32, "loss_cols"), _dev(lv, f32, "loss_targets"),
                                      _dev(ln, torch.int32, "loss_count"), _dev(z, f32, "z"), _dev(Wo, f32, "Wo"),
                                      _opt(bo, f32, "bo"), B, I, H, int(act), _dev(dz, f32, "dz"), _dev(dWo, f32, "dWo"),
-                                     _dev(dbo, f32, "dbo"), _dev(touched_items, torch.uint8, "touched_items"),
-                                     _dev(partial_loss, f32, "partial_loss"), _dev(count, torch.int32, "count"),
+                                     _dev(dbo, f32, "dbo"), _dev(partial_loss, f32, "partial_loss"), _dev(count, torch.int32, "count"),
                                      _stream()), "yr_cdae_sampled_decode")
 
 
@@ -849,7 +848,7 @@ def adam_dense_flat(tensors, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_
                     grad_count=None):
     """One launch, 16 bytes per lane, for up to ADAM_MULTI_MAX tensors of any size (yr_adam_dense_flat).
     ``tensors``: (p, g, m, v, touched, clear[, scaled]) — ``touched`` a uint8 mark per row of p (or None),
-    ``clear`` whether the gradient is zeroed after it is read, ``scaled`` whether it is first multiplied by
+    ``clear`` 1 / True: the gradient is zeroed after it is read, 2: only where it is non-zero, ``scaled`` whether it is first multiplied by
     1 / ``grad_count`` (a spread int32 count on the device)."""
     import ctypes
     lib = _lib.load()
@@ -865,7 +864,7 @@ def adam_dense_flat(tensors, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_
     counts = (ctypes.c_int64 * n)(*[t[0].numel() for t in tensors])
     marks = (ctypes.c_void_p * n)(*[_opt(t[4], torch.uint8, "touched") for t in tensors])
     widths = (ctypes.c_int * n)(*[int(t[0].shape[-1]) if t[4] is not None else 0 for t in tensors])
-    clear = (ctypes.c_int * n)(*[1 if t[5] else 0 for t in tensors])
+    clear = (ctypes.c_int * n)(*[int(t[5]) for t in tensors])
     scaled = (ctypes.c_int * n)(*[1 if len(t) > 6 and t[6] else 0 for t in tensors])
     if grad_count is not None and grad_count.numel() != COUNT_WORDS:
         raise EngineError(f"grad_count: a spread count of {COUNT_WORDS} int32 words")
