@@ -325,6 +325,20 @@ int yr_cdae_hidden_bwd(float *dz, const float *z, int act, const int64_t *user, 
 int yr_cdae_compact_pair(const float *x, const float *negative_mask, int64_t B, int64_t I, uint64_t seed,
                          double p, int32_t *cols, float *vals, int32_t *count, int32_t *loss_cols,
                          float *loss_targets, int32_t *loss_count, void *stream);
+/* yr_cdae_train_lists: a training batch as lists straight from the per-user item CSR (ptr / idx: int64, ids
+ *   ascending and distinct inside a user), no dense [B, I] row or mask (cdae_dataset.py:36-59 builds both per
+ *   user on the host): cols / vals / count = the user's items with nn.Dropout(p) applied (the mask
+ *   yr_cdae_compact_rows gives the dense row: Philox word of flat position b * I + column, seed drop_seed);
+ *   loss_* = its NS-BCE positions (column, target): the positives (1) and exactly neg_times * positives distinct
+ *   non-positive items (0), every subset equally likely (np.random.choice(replace=False), cdae_dataset.py:27:
+ *   the first distinct non-positive values of a uniform Philox sequence keyed by neg_seed and the row).  All six
+ *   buffers sized and laid out as for yr_cdae_compact_pair.  err_flag: YR_FLAG_BAD_USER, YR_FLAG_BAD_ITEM (bad or
+ *   repeated item id, or more negatives wanted than non-positives exist).  I <= 245,760. */
+int yr_cdae_train_lists(const int64_t *ptr, const int64_t *idx, const int64_t *users, int64_t B,
+                        int64_t num_users, int64_t I, int neg_times, uint64_t neg_seed,
+                        uint64_t drop_seed, double p, int32_t *cols, float *vals, int32_t *count,
+                        int32_t *loss_cols, float *loss_targets, int32_t *loss_count,
+                        int32_t *err_flag, void *stream);
 int yr_cdae_sampled_decode_splits(void);
 int yr_cdae_sampled_decode(const int32_t *loss_cols, const float *loss_targets, const int32_t *loss_count,
                            const float *z, const float *Wo, const float *bo, int64_t B, int64_t I, int H,

@@ -499,3 +499,119 @@ def test_fused_step_equals_autograd_route(device, tmp_path, ni, negative_samplin
 def engine_dropout(x, seed, p):
     from yelprecommendation_amd import engine
     return engine.dropout_seeded(x, seed, p) if p > 0 else x
+
+
+def _csr(rs, nu, ni, counts):
+    ptr = np.zeros(nu + 1, np.int64)
+    ptr[1:] = np.cumsum(counts)
+    idx = np.concatenate([np.sort(rs.choice(ni, c, replace=False)) for c in counts] or [np.zeros(0)]).astype(np.int64)
+    return ptr, idx
+
+
+@pytest.mark.parametrize("ni", [1501, 600])
+def test_train_lists_from_csr_have_the_reference_law(device, ni):
+    """yr_cdae_train_lists (a training batch as lists straight from the per-user CSR): the encoder list is exactly
+    what the dense route compacts from dropout_p(dense row); the loss list holds every positive (target 1) and
+    exactly neg_times x as many distinct non-positives (target 0), reproducible per seed, uniform over the
+    non-positives; rows with no items, rows that want more than half of the non-positives (the excluded items are
+    drawn instead), repeated users; flags for a row that wants more negatives than exist and for a bad user."""
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(ni)
+    nu, neg_times, p = 40, 5, 0.6
+    counts = rs.randint(1, 30, nu); counts[3] = 0; counts[5] = ni // 8          # 5 x (ni / 8) > half of the rest
+    ptr, idx = _csr(rs, nu, ni, counts)
+    users = rs.permutation(nu)[:24].astype(np.int64); users[:3] = (3, 5, 7); users[9] = users[10]
+    t = lambda a: torch.from_numpy(a).to(device)
+    flag = engine.new_error_flag(device)
+    L = engine.TrainLists(t(ptr), t(idx), t(users), nu, ni, neg_times, 11, 987654321, p, err_flag=flag)
+    x = np.zeros((len(users), ni), np.float32)
+    for b, u in enumerate(users):
+        x[b, idx[ptr[u]:ptr[u + 1]]] = 1.0
+    want = engine.SparseRows(t(x), 987654321, p)                                  # the dense route's lists
+    n = want.count.long()
+    assert torch.equal(L.rows.count, want.count) and torch.equal(L.rows.to_dense(), want.to_dense())
+    for b in range(len(users)):
+        assert torch.equal(L.rows.row_columns(b), want.row_columns(b))
+    target, neg = (a.cpu().numpy() for a in L.loss_dense())
+    np.testing.assert_array_equal(target, x)                                      # every positive, nothing else
+    assert float((neg * x).sum()) == 0.0
+    np.testing.assert_array_equal(neg.sum(1), neg_times * x.sum(1))
+    assert int(flag.item()) == 0
+    again = engine.TrainLists(t(ptr), t(idx), t(users), nu, ni, neg_times, 11, 5, 0.0).loss_dense()[1].cpu().numpy()
+    np.testing.assert_array_equal(again, neg)                                     # the negatives depend on neg_seed only
+    other = engine.TrainLists(t(ptr), t(idx), t(users), nu, ni, neg_times, 12, 5, 0.0).loss_dense()[1].cpu().numpy()
+    assert (other != neg).any()
+    assert (neg[9] != neg[10]).any()                                              # the same user twice: two draws
+    # uniform over the non-positives: 400 seeds on a small catalogue
+    small_ptr, small_idx = _csr(rs, 2, 97, [6, 12])
+    hits = np.zeros((2, 97))
+    for seed in range(400):
+        hits += engine.TrainLists(t(small_ptr), t(small_idx), t(np.arange(2, dtype=np.int64)), 2, 97, 3, seed, 0,
+                                  0.0).loss_dense()[1].cpu().numpy()
+    for b, k in enumerate((6, 12)):
+        free = np.setdiff1d(np.arange(97), small_idx[small_ptr[b]:small_ptr[b + 1]])
+        expect = 400 * 3 * k / len(free)
+        chi2 = float(((hits[b, free] - expect) ** 2 / expect).sum())
+        assert chi2 < len(free) + 5 * np.sqrt(2 * len(free)), (b, chi2)
+        assert hits[b].sum() == 400 * 3 * k
+    # flags: more negatives wanted than non-positives exist (np.random.choice raises there); a user out of range
+    crowded_ptr, crowded_idx = _csr(rs, 1, 40, [10])
+    C = engine.TrainLists(t(crowded_ptr), t(crowded_idx), t(np.zeros(1, np.int64)), 1, 40, 5, 1, 0, 0.0, err_flag=flag)
+    tc, nc = (a.cpu().numpy() for a in C.loss_dense())
+    assert int(flag.item()) & 2 and nc.sum() == 30 and float((tc * nc).sum()) == 0.0
+    flag.zero_()
+    engine.TrainLists(t(ptr), t(idx), t(np.array([nu + 3], np.int64)), nu, ni, neg_times, 1, 0, 0.0, err_flag=flag)
+    assert int(flag.item()) & 1
+
+
+def test_list_batches_train_like_dense_batches(device, tmp_path):
+    """CDAEStep.step_lists on engine.TrainLists == CDAEStep.step on the dense row / negative mask the lists stand
+    for (same dropout seed): losses and all parameters over three steps; then a whole trainer epoch over
+    CDAEBatchLoader(lists=True)."""
+    from yelprecommendation_amd import engine
+    from yelprecommendation_amd.cdae_step import CDAEStep
+    from yelprecommendation_amd.data.cdae_batches import CDAEBatchLoader, CDAEInteractions
+    from yelprecommendation_amd.models.cdae import CDAE
+    from yelprecommendation_amd.optim import Adam
+    from yelprecommendation_amd.trainers import CDAETrainer
+    from yelprecommendation_amd.utils import make_config
+    rs = np.random.RandomState(12)
+    nu, ni, H, B = 120, 1503, 64, 32
+    ptr, idx = _csr(rs, nu, ni, rs.randint(0, 25, nu))
+    t = lambda a: torch.from_numpy(a).to(device)
+    cfg = make_config("CDAE", hidden_size=H, device="cuda", model_dir=str(tmp_path), lr=1e-3, negative_sampling=True,
+                      neg_times=3, loss_name="bce", batch_size=B)
+    out = {}
+    for form in ("lists", "dense"):
+        torch.manual_seed(4)
+        model = CDAE(cfg, ni, nu); model.train()
+        step = CDAEStep(model, Adam(model.parameters(), lr=1e-3))
+        assert step.decoder == "sampled"
+        losses = []
+        for k in range(3):
+            users = t(np.random.RandomState(k).permutation(nu)[:B].astype(np.int64))
+            L = engine.TrainLists(t(ptr), t(idx), users, nu, ni, 3, 100 + k, 200 + k, model.corruption_level)
+            if form == "lists":
+                step.step_lists(users, L)
+            else:
+                x, neg = L.loss_dense()
+                step.step(users, x, neg, seed=200 + k, p=model.corruption_level)
+            losses.append(float(step.last_loss()))
+        step.check()
+        out[form] = (losses, [q.detach().clone() for q in model.parameters()])
+    np.testing.assert_allclose(out["lists"][0], out["dense"][0], rtol=1e-6)
+    for a, b in zip(out["lists"][1], out["dense"][1]):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+    # the loader + trainer
+    data = CDAEInteractions(nu, ni, {"train": (torch.from_numpy(ptr), torch.from_numpy(idx)),
+                                     "valid": (torch.zeros(nu + 1, dtype=torch.int64), torch.zeros(0, dtype=torch.int64)),
+                                     "test": (torch.zeros(nu + 1, dtype=torch.int64), torch.zeros(0, dtype=torch.int64))}, device)
+    trainer = CDAETrainer(cfg, ni, nu)
+    loader = CDAEBatchLoader(data, "train", batch_size=B, neg_times=3, shuffle=True, seed=1, lists=True,
+                             dropout=trainer.model.corruption_level)
+    first = trainer.train(loader)
+    for _ in range(5):
+        last = trainer.train(loader)
+    assert np.isfinite(first) and last < first and trainer._fused_step().decoder == "sampled"
+    with pytest.raises(ValueError):
+        CDAEBatchLoader(data, "valid", lists=True)

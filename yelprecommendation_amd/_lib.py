@@ -48,6 +48,8 @@ SIGNATURES = {
     "yr_cdae_decode_loss": [_p, _p, _p, _p, _p, _i64, _i64, _int, _int, _p, _i64, _p, _p, _p, _p],
     "yr_cdae_hidden_bwd": [_p, _p, _int, _p, _i64, _int, _i64, _p, _p, _p, _p, _i64, _p, _p, _p, _int, _p],
     "yr_cdae_compact_pair": [_p, _p, _i64, _i64, C.c_uint64, _d, _p, _p, _p, _p, _p, _p, _p],
+    "yr_cdae_train_lists": [_p, _p, _p, _i64, _i64, _i64, _int, C.c_uint64, C.c_uint64, _d, _p, _p, _p, _p, _p, _p,
+                            _p, _p],
     "yr_cdae_sampled_decode_splits": [],
     "yr_cdae_sampled_decode": [_p, _p, _p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p, _p, _p, _p, _p],
     "yr_cdae_hidden_init": [_p, _p, _p, _p, _i64, _int, _i64, _p, _p],

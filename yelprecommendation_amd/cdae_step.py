@@ -99,10 +99,8 @@ class CDAEStep:
             self.dz = blob[:B * H].view(B, H)
             self.count = blob[B * H:].view(torch.int32)
             self.row_count = torch.empty(B * engine.SPARSE_PARTS, dtype=torch.int32, device=dev)
+            self.loss_lists = None                        # made on the first dense batch (step_lists brings its own)
             if self.decoder == "sampled":
-                n = B * engine.SPARSE_PARTS * engine.sparse_part_columns(I)
-                self.loss_lists = (torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=f32, device=dev),
-                                   torch.empty(B * engine.SPARSE_PARTS, dtype=torch.int32, device=dev))
                 self.n_partials = B * engine.cdae_sampled_decode_splits()
             else:
                 ldg = (I + 3) // 4 * 4                                            # 16-byte rows: the gradient products
@@ -128,6 +126,11 @@ class CDAEStep:
         sampled = self.decoder == "sampled"
         if sampled and neg is None:
             raise engine.EngineError("the sampled decoder needs the negative mask")
+        if sampled and self.loss_lists is None:
+            n, dev = B * engine.SPARSE_PARTS * engine.sparse_part_columns(x.shape[1]), x.device
+            self.loss_lists = (torch.empty(n, dtype=torch.int32, device=dev),
+                               torch.empty(n, dtype=torch.float32, device=dev),
+                               torch.empty(B * engine.SPARSE_PARTS, dtype=torch.int32, device=dev))
         if sampled and x_in is None:                      # both lists of every row from one pass over x and the mask
             rows = engine.SparseRows(x, seed, p, count=self.row_count, negative_mask=neg, loss_lists=self.loss_lists)
         else:
@@ -135,10 +138,28 @@ class CDAEStep:
                 engine.SparseRows(x, 0, 0.0, count=self.row_count, negative_mask=neg, loss_lists=self.loss_lists)
             rows = engine.SparseRows(x if x_in is None else x_in.contiguous(), seed if x_in is None else 0,
                                      p if x_in is None else 0.0, count=self.row_count)
+        self._run(user_id, rows, self.loss_lists if sampled else None, x, neg)
+
+    @torch.no_grad()
+    def step_lists(self, user_id, lists):
+        """One training step on a batch that arrives as lists (engine.TrainLists from data/cdae_batches.py:
+        encoder input and loss positions straight from the per-user CSR — no dense row, no dense mask, no
+        compaction pass).  Sampled decoder only."""
+        if self.decoder != "sampled":
+            raise NotImplementedError("step_lists needs the sampled decoder (NS-BCE)")
+        if lists.B == 0:
+            return
+        self._buffers(lists.B)
+        self._run(user_id.contiguous(), lists.rows, lists.loss, None, None)
+
+    def _run(self, user_id, rows, loss_lists, x, neg):
+        model = self.model
+        Wh, bh, V, Wo, bo = (q.data for q in self.params)
+        sampled = loss_lists is not None
         engine.cdae_sparse_encode(rows, Wh, bh, V, user_id, model._hidden_act, err_flag=self.flag, out=self.z)
         self._blob.zero_()
         if sampled:
-            engine.cdae_sampled_decode(self.loss_lists, self.z, Wo, bo, model._output_act, self.dz, self.dWo,
+            engine.cdae_sampled_decode(loss_lists, self.z, Wo, bo, model._output_act, self.dz, self.dWo,
                                        self.dbo, self.partials, self.count)
         else:
             engine.cdae_decode_loss(self.z, Wo, bo, x, neg, model._output_act, self.G, self.partials, self.count)

@@ -1,0 +1,186 @@
+// CDAE training batches as LISTS, straight from the per-user item CSR (gfx950).
+//
+// The reference builds, per user and per fetch, a dense 0/1 input row and a dense negative mask over the whole
+// catalogue (data/datasets/cdae_dataset.py:20-59: np.random.choice(non-positives, neg_times * positives,
+// replace=False)); the dense route here does the same on the device (cdae_batches.hip) and the training step
+// then compacts both back into lists (cdae_sparse.hip).  At Yelp2018 size that round trip through [B, I] floats
+// is 40 % of an epoch (negative mask 66 us + dense rows 9 us + fills + compaction 17 us per 256-user batch against
+// a 150 us step).  yr_cdae_train_lists goes from the CSR to the two lists the step consumes:
+//
+//   encoder list   the user's train items with nn.Dropout(p) applied: (column, 1 / (1 - p)) for the kept ones —
+//                  the mask yr_dropout_seeded / yr_cdae_compact_rows would give the dense row (same Philox word per
+//                  flat position b * I + column), so the dense and the list route see the same corrupted input;
+//   loss list      the NS-BCE positions of the row, (column, target): its positives (1) and exactly
+//                  neg_times * positives distinct non-positive items (0), every subset equally likely.
+//
+// Negatives: the items are drawn one after the other, uniformly from the catalogue, a draw that hits a positive
+// or an item already taken is discarded — i.e. the first `need` distinct non-positive values of an i.i.d.
+// uniform sequence, which is a uniform subset (the law of np.random.choice(replace=False)).  The sequence is
+// Philox(seed; row, draw index); a round of the loop examines as many draws as are still needed (at most one
+// per thread), so it can never overshoot and the set does not depend on which thread wins a duplicate.  Taken
+// items are bits of a catalogue bitmap in LDS (4.7 KB at 38,048 items).  When more than half of the
+// non-positives are wanted the EXCLUDED ones are drawn instead.
+// Both lists come out in ascending column order in the 32-sub-list layout of cdae_sparse.hip.
+#include "common.h"
+
+namespace yr {
+
+constexpr int kListParts = 32;                  // == cdae_sparse.hip kParts
+// one workgroup of 16 waves per row: the row's work (a bitmap scan of the catalogue, 64 columns per wave step) is a
+// chain of short steps, and with 4 waves it ran at one wave per SIMD (41 us per 256 rows; the rows' CUs idle otherwise)
+constexpr int kListThreads = 1024;
+constexpr int kListWaves = kListThreads / kWave;
+
+__device__ __forceinline__ uint4 cl_philox(uint4 ctr, uint2 key, int rounds) {
+  for (int r = 0; r < rounds; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, ctr.x), lo0 = 0xD2511F53u * ctr.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, ctr.z), lo1 = 0xCD9E8D57u * ctr.z;
+    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+    key.x += 0x9E3779B9u;
+    key.y += 0xBB67AE85u;
+  }
+  return ctr;
+}
+
+__device__ __forceinline__ float cl_u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(kListThreads) void cdae_train_lists_kernel(
+    const int64_t* __restrict__ ptr, const int64_t* __restrict__ idx, const int64_t* __restrict__ users,
+    int64_t num_users, int64_t I, int neg_times, uint64_t neg_seed, uint64_t drop_seed, float p, float scale,
+    int64_t cpp, int words, int32_t* __restrict__ cols, float* __restrict__ vals, int32_t* __restrict__ count,
+    int32_t* __restrict__ lcols, float* __restrict__ lvals, int32_t* __restrict__ lcount,
+    int32_t* __restrict__ err_flag) {
+  extern __shared__ uint32_t s_bits[];            // [words] positives, then [words] drawn items
+  __shared__ int s_got, s_bad;
+  uint32_t* s_pos = s_bits;
+  uint32_t* s_drawn = s_bits + words;
+  const int64_t r = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  for (int w = tid; w < 2 * words; w += kListThreads) s_bits[w] = 0u;
+  if (tid == 0) { s_got = 0; s_bad = 0; }
+  __syncthreads();
+
+  const int64_t u = users[r];
+  int64_t lo = 0, hi = 0;
+  if ((uint64_t)u < (uint64_t)num_users) { lo = ptr[u]; hi = ptr[u + 1]; }
+  else if (tid == 0 && err_flag) atomicOr(err_flag, YR_FLAG_BAD_USER);
+  for (int64_t j = lo + tid; j < hi; j += kListThreads) {
+    const int64_t it = idx[j];
+    if ((uint64_t)it < (uint64_t)I) {
+      const uint32_t bit = 1u << (it & 31);
+      if (atomicOr(&s_pos[it >> 5], bit) & bit) s_bad = 1;      // a repeated item: the CSR is not a set
+    } else {
+      s_bad = 1;
+    }
+  }
+  __syncthreads();
+  if (s_bad && tid == 0 && err_flag) atomicOr(err_flag, YR_FLAG_BAD_ITEM);
+  // positives = bits set (repeats and out-of-range ids were flagged and do not count)
+  int npos = 0;
+  for (int w = tid; w < words; w += kListThreads) npos += __popc(s_pos[w]);
+  __shared__ int s_red[kListWaves];
+#pragma unroll
+  for (int d = kWave / 2; d >= 1; d >>= 1) npos += __shfl_xor(npos, d, kWave);
+  if (lane == 0) s_red[wave] = npos;
+  __syncthreads();
+  npos = 0;
+#pragma unroll
+  for (int w = 0; w < kListWaves; ++w) npos += s_red[w];
+
+  const int64_t room = I - npos;
+  int64_t need = (int64_t)neg_times * npos;
+  if (need > room) {                              // np.random.choice(replace=False) raises; flagged for the host
+    if (tid == 0 && err_flag) atomicOr(err_flag, YR_FLAG_BAD_ITEM);
+    need = room;
+  }
+  const bool invert = need > room / 2;            // then the items NOT taken are drawn
+  const int target = (int)(invert ? room - need : need);
+  const uint2 nkey = make_uint2((uint32_t)neg_seed, (uint32_t)(neg_seed >> 32));
+  const uint32_t span = (uint32_t)I;
+  const uint32_t lemire_min = (0u - span) % span;  // draws whose low product word is below this are biased: skipped
+  uint64_t next = 0;                              // index of the next unexamined draw of the row's sequence
+  for (;;) {
+    const int got = s_got;
+    __syncthreads();                              // everyone has read s_got before anyone adds to it
+    if (got >= target) break;
+    const int k = min(target - got, kListThreads);
+    if (tid < k) {
+      const uint64_t d = next + tid;
+      const uint4 w = cl_philox(make_uint4((uint32_t)d, (uint32_t)(d >> 32), (uint32_t)r, (uint32_t)(r >> 32)), nkey, 7);
+      const uint64_t m = (uint64_t)w.x * span;
+      if ((uint32_t)m >= lemire_min) {
+        const uint32_t it = (uint32_t)(m >> 32);
+        const uint32_t bit = 1u << (it & 31);
+        if (!(s_pos[it >> 5] & bit) && !(atomicOr(&s_drawn[it >> 5], bit) & bit)) atomicAdd(&s_got, 1);
+      }
+    }
+    next += k;
+    __syncthreads();
+  }
+
+  // emission: wave w writes parts w, w + 16; 64 columns per step, positions by ballot + prefix popcount
+  const uint2 dkey = make_uint2((uint32_t)drop_seed, (uint32_t)(drop_seed >> 32));
+  const uint64_t below = (1ull << lane) - 1ull;
+  for (int part = wave; part < kListParts; part += kListWaves) {
+    const int64_t c_lo = (int64_t)part * cpp, c_hi = min(I, c_lo + cpp);
+    const int64_t at0 = (r * kListParts + part) * cpp;
+    int base = 0, lbase = 0;
+    for (int64_t c0 = c_lo; c0 < c_hi; c0 += kWave) {
+      const int64_t c = c0 + lane;
+      bool is_pos = false, is_neg = false;
+      if (c < c_hi) {
+        const uint32_t bit = 1u << (c & 31);
+        is_pos = (s_pos[c >> 5] & bit) != 0;
+        const bool drawn = (s_drawn[c >> 5] & bit) != 0;
+        is_neg = !is_pos && (invert ? !drawn : drawn);
+      }
+      float v = 0.0f;
+      if (is_pos) {
+        v = 1.0f;
+        if (p > 0.0f) {
+          const int64_t e = r * I + c;              // flat position of the dense batch: its Philox group and word
+          const uint4 w = cl_philox(make_uint4((uint32_t)(e >> 2), (uint32_t)((e >> 2) >> 32), 0u, 0u), dkey, 10);
+          const uint32_t word = (e & 3) == 0 ? w.x : (e & 3) == 1 ? w.y : (e & 3) == 2 ? w.z : w.w;
+          v = cl_u01(word) >= p ? scale : 0.0f;
+        }
+      }
+      const uint64_t m_enc = __ballot(v != 0.0f), m_loss = __ballot(is_pos || is_neg);
+      if (v != 0.0f) {
+        const int at = base + __popcll(m_enc & below);
+        cols[at0 + at] = (int32_t)c;
+        vals[at0 + at] = v;
+      }
+      if (is_pos || is_neg) {
+        const int at = lbase + __popcll(m_loss & below);
+        lcols[at0 + at] = (int32_t)c;
+        lvals[at0 + at] = is_pos ? 1.0f : 0.0f;
+      }
+      base += __popcll(m_enc);
+      lbase += __popcll(m_loss);
+    }
+    if (lane == 0) { count[r * kListParts + part] = base; lcount[r * kListParts + part] = lbase; }
+  }
+}
+
+}  // namespace yr
+
+using namespace yr;
+
+extern "C" int yr_cdae_train_lists(const int64_t* ptr, const int64_t* idx, const int64_t* users, int64_t B,
+                                   int64_t num_users, int64_t I, int neg_times, uint64_t neg_seed, uint64_t drop_seed,
+                                   double p, int32_t* cols, float* vals, int32_t* count, int32_t* loss_cols,
+                                   float* loss_targets, int32_t* loss_count, int32_t* err_flag, void* stream) {
+  if (B < 0 || num_users <= 0 || I <= 0 || neg_times < 0 || p < 0.0 || p >= 1.0 || B > 0x7fffffff) return YR_ERR_BADARG;
+  if (I > 0x7fffffff) return YR_ERR_UNSUPPORTED;
+  if (B == 0) return 0;
+  if (!ptr || !idx || !users || !cols || !vals || !count || !loss_cols || !loss_targets || !loss_count)
+    return YR_ERR_BADARG;
+  const int words = (int)((I + 31) / 32);
+  const size_t lds = (size_t)2 * words * sizeof(uint32_t);
+  if (lds > 60 * 1024) return YR_ERR_UNSUPPORTED;        // catalogues beyond ~245 k items: the dense route
+  const int64_t cpp = ((I + kListParts - 1) / kListParts + 3) / 4 * 4;   // == yr_cdae_sparse_part_columns(I)
+  hipLaunchKernelGGL(cdae_train_lists_kernel, dim3((unsigned)B), dim3(kListThreads), lds, (hipStream_t)stream, ptr, idx,
+                     users, num_users, I, neg_times, neg_seed, drop_seed, (float)p, (float)(1.0 / (1.0 - p)), cpp, words,
+                     cols, vals, count, loss_cols, loss_targets, loss_count, err_flag);
+  return launch_status();
+}

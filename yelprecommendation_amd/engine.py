@@ -392,6 +392,40 @@ def cdae_decode_loss(z, Wo, bo, target, negative_mask, act, G, partial_loss, cou
     return G
 
 
+class TrainLists:
+    """A CDAE training batch as lists (yr_cdae_train_lists): ``rows`` — the encoder's input, a SparseRows of
+    dropout_p(train items) — and ``loss`` — (columns, targets, counts) of the NS-BCE positions (positives +
+    sampled negatives).  The buffers are sized for the worst case once per (device, B, I) and reused by the
+    next batch (one batch at a time is alive, like SparseRows)."""
+    _pool = {}
+
+    def __init__(self, ptr, idx, users, num_users, num_items, neg_times, neg_seed, drop_seed, p, err_flag=None):
+        lib = _lib.load()
+        B, I = users.numel(), int(num_items)
+        dev = users.device
+        key = (dev, B, I)
+        buf = TrainLists._pool.get(key)
+        if buf is None:
+            n, parts = B * SPARSE_PARTS * sparse_part_columns(I), B * SPARSE_PARTS
+            mk = lambda m, dt: torch.empty(m, dtype=dt, device=dev)
+            buf = (mk(n, torch.int32), mk(n, torch.float32), mk(parts, torch.int32),
+                   mk(n, torch.int32), mk(n, torch.float32), mk(parts, torch.int32))
+            TrainLists._pool = {key: buf}
+        i64 = torch.int64
+        check(lib.yr_cdae_train_lists(_dev(ptr, i64, "ptr"), _dev(idx, i64, "idx"), _dev(users, i64, "users"), B,
+                                      int(num_users), I, int(neg_times), int(neg_seed) & (2**64 - 1),
+                                      int(drop_seed) & (2**64 - 1), float(p), *(t.data_ptr() for t in buf),
+                                      _opt(err_flag, torch.int32, "err_flag"), _stream()), "yr_cdae_train_lists")
+        self.rows = SparseRows.from_buffers(buf[0], buf[1], buf[2], B, I)
+        self.loss = (buf[3], buf[4], buf[5])
+        self.B, self.I = B, I
+
+    def loss_dense(self):
+        """(target, negative_mask) [B, I] the loss lists stand for (tests)."""
+        t = SparseRows.from_buffers(self.loss[0], self.loss[1] + 1.0, self.loss[2], self.B, self.I).to_dense()
+        return (t == 2.0).float(), (t == 1.0).float()
+
+
 def cdae_sampled_decode_splits():
     return int(_lib.load().yr_cdae_sampled_decode_splits())
 
@@ -489,6 +523,14 @@ class SparseRows:
         check(lib.yr_cdae_compact_rows(_dev(x, torch.float32, "x"), B, I, int(seed) & (2**64 - 1), float(p),
                                        self.cols.data_ptr(), self.vals.data_ptr(), self.count.data_ptr(), _stream()),
               "yr_cdae_compact_rows")
+
+    @classmethod
+    def from_buffers(cls, cols, vals, count, B, I):
+        """Lists that something else filled (yr_cdae_train_lists)."""
+        self = cls.__new__(cls)
+        self.cols, self.vals, self.count, self.B, self.I = cols, vals, count, int(B), int(I)
+        self.cpp = sparse_part_columns(I)
+        return self
 
     def to_dense(self):
         """The dense matrix the lists stand for (tests)."""

@@ -69,6 +69,9 @@ class CDAETrainer(BaseTrainer):
             own_noise = "add_noise" not in model.__dict__ and type(model).add_noise is CDAE.add_noise
             step.loss_accum.zero_()
             for data in train_dataloader:
+                if 'lists' in data:                        # data/cdae_batches.py CDAEBatchLoader(lists=True)
+                    step.step_lists(data['user_id'].to(self.device), data['lists'])
+                    continue
                 user_id, input_mask = data['user_id'].to(self.device), data['input_mask'].to(self.device)
                 negative_mask = data['negative_mask'].to(self.device) if self.cfg.negative_sampling else None
                 if own_noise:
