@@ -139,7 +139,7 @@ def other_workload(args):
         x = (torch.rand(B, NI, device=dev) < 0.0008).float()                 # ~30 positives per user
         neg = (torch.rand(B, NI, device=dev) < 0.004).float() * (1 - x)      # neg_times = 5 (train_config.yaml:33)
         forms = {}
-        for form in ("sampled", "dense", "autograd"):
+        for form in ("autograd", "dense", "sampled"):
             # the trainer's step (cdae_step.py: NS-BCE -> decoder on the loss positions), the same with the
             # full-catalogue decoder on the matrix cores, and the launch-by-launch autograd route
             model = CDAE(cfg, NI, NU)
