@@ -38,8 +38,22 @@ constexpr int kEtThreads = kEtWaves * kWave;
 constexpr int kEtUsers = kEtWaves * kEtUsersPerWave;   // 128 per workgroup
 constexpr int kEtChunkItems = 64;                      // items per LDS stage (two 32-item tiles)
 constexpr int kEtMaxK = 16;
-constexpr int kEtFlushAt = 8;                          // flush when some lane holds more than this
-constexpr int kEtBufCap = kEtFlushAt + 8;              // checked after every 8 accumulator registers
+// Candidate buffers of 8 slots (flush when some lane holds more than 4, checked after every 4 accumulator
+// registers) and three catalogue slices at Yelp2018 size leave room for three workgroups per CU: 2.08 -> 1.94 ms
+// (16 slots / check every 8 / two per CU before; four per CU — 32-item stages, four slices — was slower, 2.37 ms:
+// every slice has to warm up its own thresholds).
+#ifndef YR_ET_FLUSH_AT
+#define YR_ET_FLUSH_AT 4
+#endif
+#ifndef YR_ET_CHECK_EVERY
+#define YR_ET_CHECK_EVERY 4
+#endif
+#ifndef YR_ET_TARGET_WGS
+#define YR_ET_TARGET_WGS 768
+#endif
+constexpr int kEtFlushAt = YR_ET_FLUSH_AT;             // flush when some lane holds more than this
+constexpr int kEtCheckEvery = YR_ET_CHECK_EVERY;       // ... checked after this many accumulator registers
+constexpr int kEtBufCap = kEtFlushAt + kEtCheckEvery;
 
 struct TopEntry {
   float s;
@@ -205,10 +219,10 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
       // ascending id order, so a later score EQUAL to the threshold loses the tie anyway; it also
       // keeps the -inf of the rows beyond the slice out.
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+      for (int half = 0; half < 16 / kEtCheckEvery; ++half) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int reg = half * 8 + q;
+        for (int q = 0; q < kEtCheckEvery; ++q) {
+          const int reg = half * kEtCheckEvery + q;
           float sc = acc[reg];
           if (sc > tau) {
             if (lazy_mask && ((mine >> ((reg & 3) + 8 * (reg >> 2))) & 1u)) sc = mask_value;
@@ -294,10 +308,10 @@ __global__ __launch_bounds__(kBlock) void mf_eval_merge_kernel(const TopEntry* _
 
 using namespace yr;
 
-// slices of the catalogue per 128-user workgroup row: two workgroups per CU in one round
+// slices of the catalogue per 128-user workgroup row: about three workgroups per CU in one round
 static int et_slices(int64_t nrows, int64_t num_items) {
   const int64_t rows = (nrows + kEtUsers - 1) / kEtUsers;
-  int64_t S = 512 / rows;
+  int64_t S = YR_ET_TARGET_WGS / rows;
   const int64_t by_items = num_items / 2048;          // keep slices long enough to amortise their top-k
   if (S > by_items) S = by_items;
   if (S > kEtMaxSlices) S = kEtMaxSlices;
