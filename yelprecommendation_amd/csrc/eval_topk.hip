@@ -55,6 +55,14 @@ constexpr int kEtFlushAt = YR_ET_FLUSH_AT;             // flush when some lane h
 constexpr int kEtCheckEvery = YR_ET_CHECK_EVERY;       // ... checked after this many accumulator registers
 constexpr int kEtBufCap = kEtFlushAt + kEtCheckEvery;
 
+#ifdef YR_ET_STAMPS
+// -DYR_ET_STAMPS: shader-clock cycles every wave spends per phase (scratch/eval_phases.sh), summed over the waves
+__device__ unsigned long long g_et_phase[8];
+#define ET_CLK() clock64()
+#else
+#define ET_CLK() 0ll
+#endif
+
 struct TopEntry {
   float s;
   int32_t i;
@@ -165,6 +173,7 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
       *reinterpret_cast<float4*>(dst + (q / (D / 4)) * PITCH + 4 * (q % (D / 4))) = stage[v];
     }
   };
+  [[maybe_unused]] long long ph_mfma = 0, ph_mask = 0, ph_epi = 0, ph_flush = 0, ph_sync = 0, ph_total = ET_CLK();
   fetch(item_lo);
   stash(s_items[0]);
   __syncthreads();
@@ -179,6 +188,7 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
       const int item0 = c0 + t * 32;
       if (item0 >= item_hi) break;                   // wave-uniform
       // ---- scores: acc[reg] = <item item0 + row(reg, h), user of this lane>
+      const long long t_a = ET_CLK();
       f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       {
         const float* src = chunk + (t * 32 + i) * PITCH + h * HALF;
@@ -191,8 +201,16 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, ub[4 * q + 3], acc, 0, 0, 0);
         }
       }
+#ifdef YR_ET_STAMPS
+      asm volatile("" ::"v"(acc[0]));                 // the scores have arrived
+#endif
+      const long long t_b = ET_CLK();
+      ph_mfma += t_b - t_a;
       // ---- masked items of this tile (bit r = item item0 + r), shifted to this half's rows
       uint32_t bits = 0;
+#ifdef YR_ET_EXP_NOMASK      // timing experiment only (wrong results): the mask lists are ignored
+      next_masked = 0x7fffffff;
+#endif
       while (next_masked < item0 + 32) {
         if (next_masked >= item0) bits |= 1u << (next_masked - item0);
         ++m_cur;
@@ -203,6 +221,8 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
       // lazily, inside the candidate branch only: a masked item whose real score does not beat the
       // threshold could not enter with -FLT_MAX either (the threshold is -inf, and then every
       // score is a candidate, or already >= -FLT_MAX).  Any other mask value rewrites the scores first.
+      const long long t_c = ET_CLK();
+      ph_mask += t_c - t_b;
       const uint32_t mine = bits >> (4 * h);
       if (!lazy_mask && __ballot(bits != 0) != 0ull) {
 #pragma unroll
@@ -224,7 +244,11 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
         for (int q = 0; q < kEtCheckEvery; ++q) {
           const int reg = half * kEtCheckEvery + q;
           float sc = acc[reg];
+#ifdef YR_ET_EXP_NOSCAN      // timing experiment only (wrong results): nothing ever becomes a candidate
+          if (sc == 12345.678f) {
+#else
           if (sc > tau) {
+#endif
             if (lazy_mask && ((mine >> ((reg & 3) + 8 * (reg >> 2))) & 1u)) sc = mask_value;
             if (sc > tau) {
               TopEntry c;
@@ -235,16 +259,34 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
             }
           }
         }
-        if (__ballot(cnt > kEtFlushAt) != 0ull) flush();
+        if (__ballot(cnt > kEtFlushAt) != 0ull) {
+          const long long t_f = ET_CLK();
+          flush();
+          ph_flush += ET_CLK() - t_f;
+        }
       }
+      ph_epi += ET_CLK() - t_c;
     }
+    const long long t_s = ET_CLK();
     // one barrier per chunk: everyone is done reading s_items[cur ^ 1] since the previous barrier,
     // so the next chunk can be written there while slower waves still read s_items[cur]
     if (more) stash(s_items[cur ^ 1]);
     __syncthreads();
+    ph_sync += ET_CLK() - t_s;
     cur ^= 1;
   }
   flush();
+#ifdef YR_ET_STAMPS
+  if (lane == 0) {
+    atomicAdd(&g_et_phase[0], (unsigned long long)(ET_CLK() - ph_total));
+    atomicAdd(&g_et_phase[1], (unsigned long long)ph_mfma);
+    atomicAdd(&g_et_phase[2], (unsigned long long)ph_epi);
+    atomicAdd(&g_et_phase[3], (unsigned long long)ph_flush);
+    atomicAdd(&g_et_phase[4], (unsigned long long)ph_sync);
+    atomicAdd(&g_et_phase[5], 1ull);
+    atomicAdd(&g_et_phase[6], (unsigned long long)ph_mask);
+  }
+#endif
 
   // ---- merge the two half-waves' lists of the same user (lane i <-> lane i + 32)
   {
@@ -363,3 +405,16 @@ extern "C" int yr_mf_eval_topk(const float* U, const float* I, const int64_t* us
                        partial, nrows, S, k, out);
   return launch_status();
 }
+
+#ifdef YR_ET_STAMPS
+extern "C" int yr_debug_eval_phases(unsigned long long* host_out, int reset) {
+  (void)hipDeviceSynchronize();
+  hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_et_phase), sizeof(unsigned long long) * 8);
+  if (e != hipSuccess) return (int)e;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_et_phase), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif
