@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 20
+#define YR_ENGINE_VERSION 21
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -332,14 +332,22 @@ int yr_cdae_compact_pair(const float *x, const float *negative_mask, int64_t B, 
  *   loss_* = its NS-BCE positions (column, target): the positives (1) and exactly neg_times * positives distinct
  *   non-positive items (0), every subset equally likely (np.random.choice(replace=False), cdae_dataset.py:27:
  *   the first distinct non-positive values of a uniform Philox sequence keyed by neg_seed and the row).  All six
- *   buffers sized and laid out as for yr_cdae_compact_pair.  err_flag: YR_FLAG_BAD_USER, YR_FLAG_BAD_ITEM (bad or
+ *   buffers sized and laid out as for yr_cdae_compact_pair.  ptr2 / idx2 (may be NULL): a second CSR whose items
+ *   are positives of the LOSS list as well (validation: target = train + held-out items, cdae_trainer.py:67) and
+ *   count towards neg_times, but do not enter the encoder list.  err_flag: YR_FLAG_BAD_USER, YR_FLAG_BAD_ITEM (bad or
  *   repeated item id, or more negatives wanted than non-positives exist).  I <= 245,760. */
-int yr_cdae_train_lists(const int64_t *ptr, const int64_t *idx, const int64_t *users, int64_t B,
+int yr_cdae_train_lists(const int64_t *ptr, const int64_t *idx, const int64_t *ptr2, const int64_t *idx2,
+                        const int64_t *users, int64_t B,
                         int64_t num_users, int64_t I, int neg_times, uint64_t neg_seed,
                         uint64_t drop_seed, double p, int32_t *cols, float *vals, int32_t *count,
                         int32_t *loss_cols, float *loss_targets, int32_t *loss_count,
                         int32_t *err_flag, void *stream);
 int yr_cdae_sampled_decode_splits(void);
+/* yr_cdae_sampled_decode with dz = dWo = dbo = NULL computes the loss partials and the count only (validation);
+ * yr_cdae_loss_finalize then gives stats[0] = sum(partials) / count (fixed order), stats[1] = count,
+ * *loss_accum += stats[0] (may be NULL). */
+int yr_cdae_loss_finalize(const float *partial_loss, int64_t n_partials, const int32_t *count, float *stats,
+                          double *loss_accum, void *stream);
 int yr_cdae_sampled_decode(const int32_t *loss_cols, const float *loss_targets, const int32_t *loss_count,
                            const float *z, const float *Wo, const float *bo, int64_t B, int64_t I, int H,
                            int act, float *dz, float *dWo, float *dbo, float *partial_loss,
@@ -394,6 +402,16 @@ int yr_mf_eval_topk(const float *U, const float *I, const int64_t *users, int64_
                     const int64_t *mask_ptr, const int64_t *mask_idx, float mask_value,
                     int k, int64_t *out, void *workspace, int64_t workspace_bytes,
                     int32_t *err_flag, void *stream);
+/* yr_mf_eval_topk_bias: the same with scores U[users[r]] . I[j] + item_bias[j] (item_bias NULL: yr_mf_eval_topk).
+ *   The evaluation of CDAE (trainers/cdae_trainer.py:90-144) for ALL users at once: U = the hidden rows z
+ *   [users, H], I = output_layer.weight [items, H], item_bias = output_layer.bias — sigmoid is monotone, so the
+ *   top-k of the pre-activations is the top-k of pred, and the reference's multiply-mask (seen items -> 0, below
+ *   every sigmoid output) is mask_value = -3.40282e+38 here. */
+int yr_mf_eval_topk_bias(const float *U, const float *I, const float *item_bias, const int64_t *users,
+                         int64_t nrows, int D, int64_t num_users, int64_t num_items,
+                         const int64_t *mask_ptr, const int64_t *mask_idx, float mask_value,
+                         int k, int64_t *out, void *workspace, int64_t workspace_bytes,
+                         int32_t *err_flag, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Masked row-wise top-k      (reference trainers/mf_trainer.py:163-178,

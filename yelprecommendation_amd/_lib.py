@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
-ENGINE_VERSION = 20
+ENGINE_VERSION = 21
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -48,8 +48,9 @@ SIGNATURES = {
     "yr_cdae_decode_loss": [_p, _p, _p, _p, _p, _i64, _i64, _int, _int, _p, _i64, _p, _p, _p, _p],
     "yr_cdae_hidden_bwd": [_p, _p, _int, _p, _i64, _int, _i64, _p, _p, _p, _p, _i64, _p, _p, _p, _int, _p],
     "yr_cdae_compact_pair": [_p, _p, _i64, _i64, C.c_uint64, _d, _p, _p, _p, _p, _p, _p, _p],
-    "yr_cdae_train_lists": [_p, _p, _p, _i64, _i64, _i64, _int, C.c_uint64, C.c_uint64, _d, _p, _p, _p, _p, _p, _p,
-                            _p, _p],
+    "yr_cdae_train_lists": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _int, C.c_uint64, C.c_uint64, _d, _p, _p, _p, _p, _p,
+                            _p, _p, _p],
+    "yr_cdae_loss_finalize": [_p, _i64, _p, _p, _p, _p],
     "yr_cdae_sampled_decode_splits": [],
     "yr_cdae_sampled_decode": [_p, _p, _p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p, _p, _p, _p, _p],
     "yr_cdae_hidden_init": [_p, _p, _p, _p, _i64, _int, _i64, _p, _p],
@@ -68,6 +69,7 @@ SIGNATURES = {
     "yr_mf_scores_gemm": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _p, _p],
     "yr_mf_eval_topk_workspace_bytes": [_i64, _i64, _int],
     "yr_mf_eval_topk": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _f, _int, _p, _p, _i64, _p, _p],
+    "yr_mf_eval_topk_bias": [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _f, _int, _p, _p, _i64, _p, _p],
     "yr_topk_masked": [_p, _i64, _i64, _i64, _p, _p, _p, _f, _int, _p, _p],
     "yr_rank_metrics_workspace_bytes": [_i64],
     "yr_rank_metrics": [_p, _i64, _int, _p, _p, _p, _p, _p, _p],

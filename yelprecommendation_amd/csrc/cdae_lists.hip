@@ -11,7 +11,9 @@
 //                  the mask yr_dropout_seeded / yr_cdae_compact_rows would give the dense row (same Philox word per
 //                  flat position b * I + column), so the dense and the list route see the same corrupted input;
 //   loss list      the NS-BCE positions of the row, (column, target): its positives (1) and exactly
-//                  neg_times * positives distinct non-positive items (0), every subset equally likely.
+//                  neg_times * positives distinct non-positive items (0), every subset equally likely.  With a
+//                  second CSR (validation: the held-out items, cdae_trainer.py:67 target = input + valid mask)
+//                  its items are positives of the loss list too — not of the encoder list.
 //
 // Negatives: the items are drawn one after the other, uniformly from the catalogue, a draw that hits a positive
 // or an item already taken is discarded — i.e. the first `need` distinct non-positive values of an i.i.d.
@@ -45,18 +47,20 @@ __device__ __forceinline__ uint4 cl_philox(uint4 ctr, uint2 key, int rounds) {
 __device__ __forceinline__ float cl_u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
 __global__ __launch_bounds__(kListThreads) void cdae_train_lists_kernel(
-    const int64_t* __restrict__ ptr, const int64_t* __restrict__ idx, const int64_t* __restrict__ users,
-    int64_t num_users, int64_t I, int neg_times, uint64_t neg_seed, uint64_t drop_seed, float p, float scale,
+    const int64_t* __restrict__ ptr, const int64_t* __restrict__ idx, const int64_t* __restrict__ ptr2,
+    const int64_t* __restrict__ idx2, const int64_t* __restrict__ users, int64_t num_users, int64_t I, int neg_times, uint64_t neg_seed, uint64_t drop_seed, float p, float scale,
     int64_t cpp, int words, int32_t* __restrict__ cols, float* __restrict__ vals, int32_t* __restrict__ count,
     int32_t* __restrict__ lcols, float* __restrict__ lvals, int32_t* __restrict__ lcount,
     int32_t* __restrict__ err_flag) {
-  extern __shared__ uint32_t s_bits[];            // [words] positives, then [words] drawn items
+  extern __shared__ uint32_t s_bits[];            // [words] input items, [words] drawn items, [words] all positives
   __shared__ int s_got, s_bad;
-  uint32_t* s_pos = s_bits;
+  uint32_t* s_in = s_bits;                        // the encoder's input: the items of (ptr, idx)
   uint32_t* s_drawn = s_bits + words;
+  uint32_t* s_pos = ptr2 ? s_bits + 2 * words : s_bits;   // loss positives: input items + those of (ptr2, idx2)
+  const int nmaps = ptr2 ? 3 : 2;
   const int64_t r = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  for (int w = tid; w < 2 * words; w += kListThreads) s_bits[w] = 0u;
+  for (int w = tid; w < nmaps * words; w += kListThreads) s_bits[w] = 0u;
   if (tid == 0) { s_got = 0; s_bad = 0; }
   __syncthreads();
 
@@ -68,9 +72,17 @@ __global__ __launch_bounds__(kListThreads) void cdae_train_lists_kernel(
     const int64_t it = idx[j];
     if ((uint64_t)it < (uint64_t)I) {
       const uint32_t bit = 1u << (it & 31);
-      if (atomicOr(&s_pos[it >> 5], bit) & bit) s_bad = 1;      // a repeated item: the CSR is not a set
+      if (atomicOr(&s_in[it >> 5], bit) & bit) s_bad = 1;       // a repeated item: the CSR is not a set
+      if (ptr2) atomicOr(&s_pos[it >> 5], bit);
     } else {
       s_bad = 1;
+    }
+  }
+  if (ptr2 && (uint64_t)u < (uint64_t)num_users) {
+    for (int64_t j = ptr2[u] + tid; j < ptr2[u + 1]; j += kListThreads) {
+      const int64_t it = idx2[j];
+      if ((uint64_t)it < (uint64_t)I) atomicOr(&s_pos[it >> 5], 1u << (it & 31));
+      else s_bad = 1;
     }
   }
   __syncthreads();
@@ -127,15 +139,16 @@ __global__ __launch_bounds__(kListThreads) void cdae_train_lists_kernel(
     int base = 0, lbase = 0;
     for (int64_t c0 = c_lo; c0 < c_hi; c0 += kWave) {
       const int64_t c = c0 + lane;
-      bool is_pos = false, is_neg = false;
+      bool is_pos = false, is_neg = false, is_in = false;
       if (c < c_hi) {
         const uint32_t bit = 1u << (c & 31);
         is_pos = (s_pos[c >> 5] & bit) != 0;
+        is_in = (s_in[c >> 5] & bit) != 0;
         const bool drawn = (s_drawn[c >> 5] & bit) != 0;
         is_neg = !is_pos && (invert ? !drawn : drawn);
       }
       float v = 0.0f;
-      if (is_pos) {
+      if (is_in) {
         v = 1.0f;
         if (p > 0.0f) {
           const int64_t e = r * I + c;              // flat position of the dense batch: its Philox group and word
@@ -166,21 +179,22 @@ __global__ __launch_bounds__(kListThreads) void cdae_train_lists_kernel(
 
 using namespace yr;
 
-extern "C" int yr_cdae_train_lists(const int64_t* ptr, const int64_t* idx, const int64_t* users, int64_t B,
+extern "C" int yr_cdae_train_lists(const int64_t* ptr, const int64_t* idx, const int64_t* ptr2, const int64_t* idx2,
+                                   const int64_t* users, int64_t B,
                                    int64_t num_users, int64_t I, int neg_times, uint64_t neg_seed, uint64_t drop_seed,
                                    double p, int32_t* cols, float* vals, int32_t* count, int32_t* loss_cols,
                                    float* loss_targets, int32_t* loss_count, int32_t* err_flag, void* stream) {
   if (B < 0 || num_users <= 0 || I <= 0 || neg_times < 0 || p < 0.0 || p >= 1.0 || B > 0x7fffffff) return YR_ERR_BADARG;
   if (I > 0x7fffffff) return YR_ERR_UNSUPPORTED;
   if (B == 0) return 0;
-  if (!ptr || !idx || !users || !cols || !vals || !count || !loss_cols || !loss_targets || !loss_count)
+  if (!ptr || !idx || !users || (ptr2 && !idx2) || !cols || !vals || !count || !loss_cols || !loss_targets || !loss_count)
     return YR_ERR_BADARG;
   const int words = (int)((I + 31) / 32);
-  const size_t lds = (size_t)2 * words * sizeof(uint32_t);
+  const size_t lds = (size_t)(ptr2 ? 3 : 2) * words * sizeof(uint32_t);
   if (lds > 60 * 1024) return YR_ERR_UNSUPPORTED;        // catalogues beyond ~245 k items: the dense route
   const int64_t cpp = ((I + kListParts - 1) / kListParts + 3) / 4 * 4;   // == yr_cdae_sparse_part_columns(I)
-  hipLaunchKernelGGL(cdae_train_lists_kernel, dim3((unsigned)B), dim3(kListThreads), lds, (hipStream_t)stream, ptr, idx,
-                     users, num_users, I, neg_times, neg_seed, drop_seed, (float)p, (float)(1.0 / (1.0 - p)), cpp, words,
+  hipLaunchKernelGGL(cdae_train_lists_kernel, dim3((unsigned)B), dim3(kListThreads), lds, (hipStream_t)stream, ptr, idx, ptr2,
+                     idx2, users, num_users, I, neg_times, neg_seed, drop_seed, (float)p, (float)(1.0 / (1.0 - p)), cpp, words,
                      cols, vals, count, loss_cols, loss_targets, loss_count, err_flag);
   return launch_status();
 }

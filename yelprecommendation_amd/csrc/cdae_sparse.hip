@@ -279,6 +279,7 @@ __global__ __launch_bounds__(kBlock) void cdae_sampled_decode_kernel(
   }
   float loss = 0.0f;
   int done = 0;
+  const bool grads = dWo != nullptr;              // NULL gradient buffers: the loss only (validation)
   for (int skip = 0;; skip += kListCap) {
     const int n = gather_row_list(lcols, lvals, lcount, cpp, r, skip, s_pre, s_col, s_val);
     // this workgroup's share of the staged entries: j = split, split + splits, ...; half-wave `half` takes every
@@ -310,12 +311,14 @@ __global__ __launch_bounds__(kBlock) void cdae_sampled_decode_kernel(
         float g = (y - t) / fmaxf((1.0f - y) * y, 1e-12f);
         if (act == 1) g *= y * (1.0f - y);
         ++done;
+        if (grads) {
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-          acc[k] += g * (which ? w1[k] : w0[k]);
-          if (in[k]) atomicAdd(dWo + (int64_t)col * H + lane + kHalf * k, g * zr[k]);
+          for (int k = 0; k < NK; ++k) {
+            acc[k] += g * (which ? w1[k] : w0[k]);
+            if (in[k]) atomicAdd(dWo + (int64_t)col * H + lane + kHalf * k, g * zr[k]);
+          }
+          if (lane == 0) atomicAdd(dbo + col, g);
         }
-        if (lane == 0) atomicAdd(dbo + col, g);
       }
     }
     const bool more = skip + n < s_pre[kParts];
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(kBlock) void cdae_sampled_decode_kernel(
   for (int k = 0; k < NK; ++k) s_dz[half][lane + kHalf * k] = acc[k];
   if (lane == 0) { s_loss[half] = loss; s_done[half] = done; }
   __syncthreads();
-  for (int h = threadIdx.x; h < H; h += kBlock) {
+  for (int h = threadIdx.x; grads && h < H; h += kBlock) {
     float tsum = 0.0f;
 #pragma unroll
     for (int k = 0; k < kHalves; ++k) tsum += s_dz[k][h];
@@ -341,6 +344,23 @@ __global__ __launch_bounds__(kBlock) void cdae_sampled_decode_kernel(
     for (int k = 0; k < kHalves; ++k) { tl += s_loss[k]; tot += s_done[k]; }
     partial_loss[r * splits + split] = tl;
     spread_count_add(count, blockIdx.y * gridDim.x + blockIdx.x, tot);
+  }
+}
+
+// stats[0] = (sum of the partials, fixed order) / count, stats[1] = count, *loss_accum += stats[0]
+__global__ __launch_bounds__(kBlock) void cdae_loss_finalize_kernel(const float* __restrict__ partial_loss,
+                                                                    int64_t n_partials, const int32_t* __restrict__ count,
+                                                                    float* __restrict__ stats, double* __restrict__ loss_accum) {
+  __shared__ float s_red[kWavesPerBlock];
+  float s = 0.0f;
+  for (int64_t k = threadIdx.x; k < n_partials; k += kBlock) s += partial_loss[k];
+  const int32_t c = spread_count(count, threadIdx.x & (kWave - 1));
+  const float tot = block_sum(s, s_red);
+  if (threadIdx.x == 0) {
+    const float mean = c > 0 ? tot / (float)c : 0.0f;
+    stats[0] = mean;
+    stats[1] = (float)c;
+    if (loss_accum) loss_accum[0] += (double)mean;
   }
 }
 
@@ -418,8 +438,8 @@ extern "C" int yr_cdae_sampled_decode(const int32_t* loss_cols, const float* los
   if (B < 0 || I <= 0 || H <= 0 || (act != 0 && act != 1)) return YR_ERR_BADARG;
   if (H > 256) return YR_ERR_UNSUPPORTED;
   if (B == 0) return 0;
-  if (!loss_cols || !loss_targets || !loss_count || !z || !Wo || !dz || !dWo || !dbo || !partial_loss || !count)
-    return YR_ERR_BADARG;
+  if (!loss_cols || !loss_targets || !loss_count || !z || !Wo || !partial_loss || !count) return YR_ERR_BADARG;
+  if ((dz || dWo || dbo) && !(dz && dWo && dbo)) return YR_ERR_BADARG;      // all three gradients or none
   if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(Wo)) & 15) return YR_ERR_BADARG;
   const int splits = yr_cdae_sampled_decode_splits();
   const int64_t cpp = yr_cdae_sparse_part_columns(I);
@@ -431,5 +451,13 @@ extern "C" int yr_cdae_sampled_decode(const int32_t* loss_cols, const float* los
   else
     hipLaunchKernelGGL((cdae_sampled_decode_kernel<8>), grid, dim3(kBlock), 0, s, loss_cols, loss_targets, loss_count,
                        cpp, z, Wo, bo, H, act, splits, dz, dWo, dbo, partial_loss, count);
+  return launch_status();
+}
+
+extern "C" int yr_cdae_loss_finalize(const float* partial_loss, int64_t n_partials, const int32_t* count, float* stats,
+                                     double* loss_accum, void* stream) {
+  if (n_partials < 0 || !partial_loss || !count || !stats) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(cdae_loss_finalize_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, partial_loss, n_partials,
+                     count, stats, loss_accum);
   return launch_status();
 }

@@ -87,9 +87,13 @@ __device__ __forceinline__ void et_bubble(float (&Ls)[KK], int32_t (&Li)[KK], fl
   }
 }
 
-template <int D, int KK>
+// BIAS: score = <user, item> + item_bias[item] — the decoder of CDAE, z . W_o[i] + b_o[i] (models/cdae.py:52), whose
+// sigmoid is monotone, so the top-k of the pre-activations is the top-k of the predictions.  The bias enters as
+// the initial value of the MFMA accumulator (staged through LDS with the item chunk): no extra instruction per score.
+template <int D, int KK, bool BIAS>
 __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
-    const float* __restrict__ U, const float* __restrict__ I, const int64_t* __restrict__ users, int64_t nrows,
+    const float* __restrict__ U, const float* __restrict__ I, const float* __restrict__ item_bias,
+    const int64_t* __restrict__ users, int64_t nrows,
     int64_t num_users, int num_items, const int64_t* __restrict__ mask_ptr, const int64_t* __restrict__ mask_idx,
     float mask_value, int k, int64_t* __restrict__ out, TopEntry* __restrict__ partial, int items_per_slice,
     int32_t* __restrict__ err_flag) {
@@ -99,6 +103,7 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
   static_assert(NV >= 1, "chunk too small for this D");
   __shared__ __attribute__((aligned(16))) float s_items[2][kEtChunkItems * PITCH];   // double-buffered
   __shared__ TopEntry s_buf[kEtBufCap][kEtThreads];               // slot-major: conflict-free per slot
+  __shared__ __attribute__((aligned(16))) float s_bias[2][BIAS ? kEtChunkItems : 4];
 
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int i = lane & 31, h = lane >> 5;
@@ -157,7 +162,10 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
   // register staging of the item chunks: the loads of chunk c+1 are issued before the tiles of
   // chunk c are computed and land in LDS after the next barrier (global latency hidden under MFMA)
   float4 stage[NV];
+  float stage_b = 0.0f;
   auto fetch = [&](int c0) {
+    if (BIAS && threadIdx.x < kEtChunkItems)
+      stage_b = c0 + (int)threadIdx.x < item_hi ? item_bias[c0 + threadIdx.x] : 0.0f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int q = threadIdx.x + v * kEtThreads;
@@ -166,7 +174,8 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
       if (c0 + r < item_hi) stage[v] = *reinterpret_cast<const float4*>(I + (int64_t)(c0 + r) * D + 4 * c);
     }
   };
-  auto stash = [&](float* dst) {
+  auto stash = [&](float* dst, int buf) {
+    if (BIAS && threadIdx.x < kEtChunkItems) s_bias[buf][threadIdx.x] = stage_b;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int q = threadIdx.x + v * kEtThreads;
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
   };
   [[maybe_unused]] long long ph_mfma = 0, ph_mask = 0, ph_epi = 0, ph_flush = 0, ph_sync = 0, ph_total = ET_CLK();
   fetch(item_lo);
-  stash(s_items[0]);
+  stash(s_items[0], 0);
   __syncthreads();
   int cur = 0;
   for (int c0 = item_lo; c0 < item_hi; c0 += kEtChunkItems) {
@@ -190,6 +199,13 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
       // ---- scores: acc[reg] = <item item0 + row(reg, h), user of this lane>
       const long long t_a = ET_CLK();
       f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (BIAS) {                                    // accumulator register 4 g + j holds item 8 g + 4 h + j of the tile
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b4 = *reinterpret_cast<const float4*>(&s_bias[cur][t * 32 + 8 * g + 4 * h]);
+          acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
+        }
+      }
       {
         const float* src = chunk + (t * 32 + i) * PITCH + h * HALF;
 #pragma unroll
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
     const long long t_s = ET_CLK();
     // one barrier per chunk: everyone is done reading s_items[cur ^ 1] since the previous barrier,
     // so the next chunk can be written there while slower waves still read s_items[cur]
-    if (more) stash(s_items[cur ^ 1]);
+    if (more) stash(s_items[cur ^ 1], cur ^ 1);
     __syncthreads();
     ph_sync += ET_CLK() - t_s;
     cur ^= 1;
@@ -366,10 +382,11 @@ extern "C" int64_t yr_mf_eval_topk_workspace_bytes(int64_t nrows, int64_t num_it
   return S > 1 ? nrows * S * k * (int64_t)sizeof(TopEntry) : 0;
 }
 
-extern "C" int yr_mf_eval_topk(const float* U, const float* I, const int64_t* users, int64_t nrows, int D,
-                               int64_t num_users, int64_t num_items, const int64_t* mask_ptr,
-                               const int64_t* mask_idx, float mask_value, int k, int64_t* out, void* workspace,
-                               int64_t workspace_bytes, int32_t* err_flag, void* stream) {
+extern "C" int yr_mf_eval_topk_bias(const float* U, const float* I, const float* item_bias, const int64_t* users,
+                                    int64_t nrows, int D, int64_t num_users, int64_t num_items,
+                                    const int64_t* mask_ptr, const int64_t* mask_idx, float mask_value, int k,
+                                    int64_t* out, void* workspace, int64_t workspace_bytes, int32_t* err_flag,
+                                    void* stream) {
   if (nrows < 0 || num_users <= 0 || num_items <= 0 || num_items > 0x7ffffff0 || k <= 0 || k > kEtMaxK)
     return YR_ERR_BADARG;
   if (nrows == 0) return 0;
@@ -382,9 +399,14 @@ extern "C" int yr_mf_eval_topk(const float* U, const float* I, const int64_t* us
   TopEntry* partial = S > 1 ? static_cast<TopEntry*>(workspace) : nullptr;
   const dim3 grid((unsigned)((nrows + kEtUsers - 1) / kEtUsers), (unsigned)S);
   hipStream_t s = (hipStream_t)stream;
-#define YR_ET_LAUNCH(DD, KK)                                                                                    \
-  hipLaunchKernelGGL((mf_eval_topk_kernel<DD, KK>), grid, dim3(kEtThreads), 0, s, U, I, users, nrows,           \
+#define YR_ET_LAUNCH_B(DD, KK, BB)                                                                                \
+  hipLaunchKernelGGL((mf_eval_topk_kernel<DD, KK, BB>), grid, dim3(kEtThreads), 0, s, U, I, item_bias, users, nrows, \
                      num_users, (int)num_items, mask_ptr, mask_idx, mask_value, k, out, partial, per, err_flag)
+#define YR_ET_LAUNCH(DD, KK)                    \
+  do {                                          \
+    if (item_bias) YR_ET_LAUNCH_B(DD, KK, true); \
+    else YR_ET_LAUNCH_B(DD, KK, false);         \
+  } while (0)
 #define YR_ET_CASE(DD)                                     \
   case DD:                                                 \
     if (k <= 4) YR_ET_LAUNCH(DD, 4);                       \
@@ -400,10 +422,19 @@ extern "C" int yr_mf_eval_topk(const float* U, const float* I, const int64_t* us
   }
 #undef YR_ET_CASE
 #undef YR_ET_LAUNCH
+#undef YR_ET_LAUNCH_B
   if (S > 1)
     hipLaunchKernelGGL(mf_eval_merge_kernel, dim3((unsigned)((nrows + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
                        partial, nrows, S, k, out);
   return launch_status();
+}
+
+extern "C" int yr_mf_eval_topk(const float* U, const float* I, const int64_t* users, int64_t nrows, int D,
+                               int64_t num_users, int64_t num_items, const int64_t* mask_ptr,
+                               const int64_t* mask_idx, float mask_value, int k, int64_t* out, void* workspace,
+                               int64_t workspace_bytes, int32_t* err_flag, void* stream) {
+  return yr_mf_eval_topk_bias(U, I, nullptr, users, nrows, D, num_users, num_items, mask_ptr, mask_idx, mask_value, k,
+                              out, workspace, workspace_bytes, err_flag, stream);
 }
 
 #ifdef YR_ET_STAMPS

@@ -126,14 +126,15 @@ class CDAEBatchLoader:
 
     def __init__(self, data: CDAEInteractions, mode="train", batch_size=32, neg_times=5, shuffle=False, seed=0,
                  lists=False, dropout=0.0):
-        """``lists=True`` (mode 'train'): a batch is ``{"user_id", "lists"}`` with ``lists`` an engine.TrainLists —
-        the encoder's input (the user's train items after nn.Dropout(``dropout``)) and the NS-BCE positions
-        (positives + ``neg_times`` x as many sampled negatives) as per-row lists made straight from the CSR
-        (yr_cdae_train_lists); no dense row or mask exists.  ``CDAETrainer.train`` feeds them to the fused step."""
+        """``lists=True``: a batch is ``{"user_id", "lists"[, "item_lists"]}`` with ``lists`` an engine.TrainLists —
+        the encoder's input and the NS-BCE positions (positives + ``neg_times`` x as many sampled negatives) as
+        per-row lists made straight from the CSR (yr_cdae_train_lists); no dense row or mask exists.
+        'train': input = train items after nn.Dropout(``dropout``), positives = train items (CDAETrainer.train feeds
+        the fused step); 'valid': input = train items, positives = train + held-out items; 'test': input = train +
+        valid items, no loss list.  CDAETrainer.validate / evaluate then score all users at once with the fused
+        evaluation kernel."""
         if mode not in ("train", "valid", "test"):
             raise ValueError(f"mode {mode!r}")
-        if lists and mode != "train":
-            raise ValueError("list batches exist for training only (evaluation reads whole catalogue rows)")
         self.data, self.mode, self.batch_size, self.neg_times, self.shuffle = data, mode, int(batch_size), neg_times, shuffle
         self.lists, self.dropout = bool(lists), float(dropout)
         self._gen = torch.Generator(device=data.device).manual_seed(seed)
@@ -162,12 +163,17 @@ class CDAEBatchLoader:
                 lists.update(actual=d.csr("valid"), seen=d.csr("train"))
             elif self.mode == "test":
                 lists.update(actual=d.csr("test"), seen=d.csr("train_valid"))
-            if self.mode == "train" and self.lists:
-                ptr, idx = d.csr("train")
+            if self.lists:
                 seeds = torch.randint(0, 1 << 62, (2,), generator=self._seeds).tolist()
-                yield {"user_id": users, "lists": engine.TrainLists(ptr, idx, users.contiguous(), d.num_users, d.num_items,
-                                                                   self.neg_times, seeds[0], seeds[1], self.dropout,
-                                                                   err_flag=self._flag)}
+                ptr, idx = d.csr("train_valid" if self.mode == "test" else "train")
+                made = engine.TrainLists(ptr, idx, users.contiguous(), d.num_users, d.num_items,
+                                         0 if self.mode == "test" else self.neg_times, seeds[0], seeds[1],
+                                         self.dropout if self.mode == "train" else 0.0, err_flag=self._flag,
+                                         extra=d.csr("valid") if self.mode == "valid" else None)
+                batch = {"user_id": users, "lists": made}
+                if self.mode != "train":
+                    batch["item_lists"] = lists
+                yield batch
             elif self.mode == "train":
                 x = d.dense("train", users)
                 yield {"user_id": users, "input_mask": x, "negative_mask": self.negative_mask(x)}

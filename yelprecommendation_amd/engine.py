@@ -399,7 +399,10 @@ class TrainLists:
     next batch (one batch at a time is alive, like SparseRows)."""
     _pool = {}
 
-    def __init__(self, ptr, idx, users, num_users, num_items, neg_times, neg_seed, drop_seed, p, err_flag=None):
+    def __init__(self, ptr, idx, users, num_users, num_items, neg_times, neg_seed, drop_seed, p, err_flag=None,
+                 extra=None):
+        """``extra``: (ptr, idx) of a second per-user CSR whose items are positives of the loss list too (the
+        held-out items in validation) without entering the encoder list."""
         lib = _lib.load()
         B, I = users.numel(), int(num_items)
         dev = users.device
@@ -412,7 +415,9 @@ class TrainLists:
                    mk(n, torch.int32), mk(n, torch.float32), mk(parts, torch.int32))
             TrainLists._pool = {key: buf}
         i64 = torch.int64
-        check(lib.yr_cdae_train_lists(_dev(ptr, i64, "ptr"), _dev(idx, i64, "idx"), _dev(users, i64, "users"), B,
+        check(lib.yr_cdae_train_lists(_dev(ptr, i64, "ptr"), _dev(idx, i64, "idx"),
+                                      None if extra is None else _dev(extra[0], i64, "ptr2"),
+                                      None if extra is None else _dev(extra[1], i64, "idx2"), _dev(users, i64, "users"), B,
                                       int(num_users), I, int(neg_times), int(neg_seed) & (2**64 - 1),
                                       int(drop_seed) & (2**64 - 1), float(p), *(t.data_ptr() for t in buf),
                                       _opt(err_flag, torch.int32, "err_flag"), _stream()), "yr_cdae_train_lists")
@@ -432,7 +437,8 @@ def cdae_sampled_decode_splits():
 
 def cdae_sampled_decode(loss_lists, z, Wo, bo, act, dz, dWo, dbo, partial_loss, count):
     """Decoder forward + loss + all three decoder gradients on the loss positions only (yr_cdae_sampled_decode);
-    everything it adds to comes out WITHOUT the 1 / count of the mean loss."""
+    everything it adds to comes out WITHOUT the 1 / count of the mean loss.  ``dz = dWo = dbo = None``: the loss
+    partials and the count only (validation)."""
     lib = _lib.load()
     f32 = torch.float32
     lc, lv, ln = loss_lists
@@ -442,9 +448,17 @@ def cdae_sampled_decode(loss_lists, z, Wo, bo, act, dz, dWo, dbo, partial_loss, 
         raise EngineError("bad buffers for cdae_sampled_decode")
     check(lib.yr_cdae_sampled_decode(_dev(lc, torch.int32, "loss_cols"), _dev(lv, f32, "loss_targets"),
                                      _dev(ln, torch.int32, "loss_count"), _dev(z, f32, "z"), _dev(Wo, f32, "Wo"),
-                                     _opt(bo, f32, "bo"), B, I, H, int(act), _dev(dz, f32, "dz"), _dev(dWo, f32, "dWo"),
-                                     _dev(dbo, f32, "dbo"), _dev(partial_loss, f32, "partial_loss"), _dev(count, torch.int32, "count"),
+                                     _opt(bo, f32, "bo"), B, I, H, int(act), _opt(dz, f32, "dz"), _opt(dWo, f32, "dWo"),
+                                     _opt(dbo, f32, "dbo"), _dev(partial_loss, f32, "partial_loss"), _dev(count, torch.int32, "count"),
                                      _stream()), "yr_cdae_sampled_decode")
+
+
+def cdae_loss_finalize(partial_loss, n_partials, count, stats, loss_accum=None):
+    """stats[0] = sum(partials) / count, stats[1] = count; ``loss_accum`` (float64 device scalar) += stats[0]."""
+    lib = _lib.load()
+    check(lib.yr_cdae_loss_finalize(_dev(partial_loss, torch.float32, "partial_loss"), int(n_partials),
+                                    _dev(count, torch.int32, "count"), _dev(stats, torch.float32, "stats"),
+                                    _opt(loss_accum, torch.float64, "loss_accum"), _stream()), "yr_cdae_loss_finalize")
 
 
 def cdae_hidden_bwd(dz, z, act, user, dV, touched_users, dbh, partial_loss=None, n_partials=0, count=None,
@@ -718,10 +732,12 @@ def sort_mask_rows(mask_ptr, mask_idx):
     return mask_idx[order].contiguous()
 
 
-def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALUE, out=None, sliced=True):
+def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALUE, out=None, sliced=True,
+                 item_bias=None):
     """Fused full-catalogue scoring + mask + top-k (no score matrix).  ``mask_idx_sorted``: CSR mask
     lists with ascending ids inside each row (see :func:`sort_mask_rows`).  ``sliced=False`` withholds
-    the workspace, i.e. forces the one-slice form of the kernel (tests)."""
+    the workspace, i.e. forces the one-slice form of the kernel (tests).  ``item_bias``: scores
+    U[u] . I[j] + item_bias[j] (the CDAE decoder before its sigmoid)."""
     lib = _lib.load()
     nu, ni, d = _table_dims(U, I)
     n = users.numel()
@@ -732,7 +748,8 @@ def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALU
     if ws_bytes < 0:
         check(int(ws_bytes), "yr_mf_eval_topk_workspace_bytes")
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=U.device) if ws_bytes else None
-    check(lib.yr_mf_eval_topk(_dev(U, torch.float32, "U"), _dev(I, torch.float32, "I"),
+    check(lib.yr_mf_eval_topk_bias(_dev(U, torch.float32, "U"), _dev(I, torch.float32, "I"),
+                              _opt(item_bias, torch.float32, "item_bias"),
                               _dev(users, torch.int64, "users"), n, d, nu, ni,
                               _opt(mask_ptr, torch.int64, "mask_ptr"), _opt(mask_idx_sorted, torch.int64, "mask_idx"),
                               float(mask_value), int(k), _dev(out, torch.int64, "out"),

@@ -99,10 +99,56 @@ class CDAETrainer(BaseTrainer):
         self.model.check_indices()
         return float(self._loss_accum.item())
 
+    def _scored_by_lists(self, dataloader, with_loss):
+        """validate / evaluate over list batches (CDAEBatchLoader(lists=True)): per batch only the encoder runs
+        (and, in validation, the NS-BCE terms on the loss positions: yr_cdae_sampled_decode without gradients);
+        the hidden rows of ALL users are then scored against the whole catalogue in one launch of the fused
+        evaluation kernel — z . W_o[i] + b_o[i] on the matrix cores with the seen-item mask and the top-k in the
+        epilogue (yr_mf_eval_topk_bias), no [B, I] prediction — and the metrics in one more.  The output
+        activation is monotone, so the top-k of the pre-activations is the reference's top-k of ``pred``; its
+        multiply-mask (seen items -> 0, cdae_trainer.py:132) is below every sigmoid output, i.e. -FLT_MAX before
+        the sigmoid (with the identity activation: the value 0 itself).
+        Returns the six metric sums of _metric_sums over the whole user set."""
+        model, dev = self.model, self.device
+        if with_loss and not self.cfg.negative_sampling:
+            raise NotImplementedError("list batches carry the NS-BCE positions; plain BCE needs dense batches")
+        Wh, bh, V, Wo, bo = (q.data for q in model._params())
+        Z = torch.zeros(model.num_users, model.hidden_size, dtype=torch.float32, device=dev)   # rows by user id
+        covered, item_lists = 0, None
+        stats = torch.zeros(2, dtype=torch.float32, device=dev)
+        count = torch.zeros(engine.COUNT_WORDS, dtype=torch.int32, device=dev)
+        partials = None
+        for data in dataloader:
+            users, lists = data['user_id'].to(dev).contiguous(), data['lists']
+            z = engine.cdae_sparse_encode(lists.rows, Wh, bh, V, users, model._hidden_act, err_flag=model._flag())
+            Z.index_copy_(0, users, z)
+            covered += users.numel()
+            item_lists = data['item_lists']
+            if with_loss:
+                n = users.numel() * engine.cdae_sampled_decode_splits()
+                if partials is None or partials.numel() < n:
+                    partials = torch.empty(n, dtype=torch.float32, device=dev)
+                count.zero_()
+                engine.cdae_sampled_decode(lists.loss, z, Wo, bo, model._output_act, None, None, None, partials, count)
+                engine.cdae_loss_finalize(partials, n, count, stats, self._loss_accum)
+        if covered != model.num_users or item_lists is None:
+            raise NotImplementedError("list batches must cover every user exactly once (CDAEBatchLoader does)")
+        (sp, si), (ap, ai) = item_lists["seen"], item_lists["actual"]
+        mask_value = engine.MASK_VALUE if model._output_act == engine.ACT_SIGMOID else 0.0
+        top = engine.mf_eval_topk(Z, Wo, torch.arange(model.num_users, device=dev), sp, si, self.cfg.top_n,
+                                  mask_value=mask_value, item_bias=bo)
+        model.check_indices()
+        return engine.rank_metrics(top, ap, ai)[4:10]
+
     def validate(self, valid_dataloader):
         # reference cdae_trainer.py:56-88
         self.model.eval()
         self._loss_accum.zero_()
+        if getattr(valid_dataloader, "lists", False):
+            with torch.no_grad():
+                sums = self._scored_by_lists(valid_dataloader, with_loss=True)
+            p, r, m, n = self._metrics(False, None, None, sums)
+            return (float(self._loss_accum.item()), p, r, m, n)
         actual, predicted = [], []
         host = self.cfg.get("host_metrics", False)
         sums = torch.zeros(6, dtype=torch.float64, device=self.device)
@@ -131,6 +177,13 @@ class CDAETrainer(BaseTrainer):
     def evaluate(self, test_dataloader):
         # reference cdae_trainer.py:90-121
         self.model.eval()
+        if getattr(test_dataloader, "lists", False):
+            with torch.no_grad():
+                sums = self._scored_by_lists(test_dataloader, with_loss=False)
+            p, r, m, n = self._metrics(False, None, None, sums)
+            logger.info(f"[Trainer] Test > precision@{self.cfg.top_n} : {p:.4f} / Recall@{self.cfg.top_n}: {r:.4f} / "
+                        f"MAP@{self.cfg.top_n}: {m:.4f} / NDCG@{self.cfg.top_n}: {n:.4f}")
+            return (p, r, m, n)
         actual, predicted = [], []
         host = self.cfg.get("host_metrics", False)
         sums = torch.zeros(6, dtype=torch.float64, device=self.device)
