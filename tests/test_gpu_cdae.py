@@ -685,3 +685,15 @@ def test_list_route_of_validate_and_evaluate_equals_dense_route(device, tmp_path
     spn, sin = sp.cpu().numpy(), si.cpu().numpy()
     masked = [sin[spn[r]:spn[r + 1]] for r in range(nu)]
     assert_topk_equal_up_to_near_ties(top_fused.cpu().numpy(), top_dense.cpu().numpy(), Ua, Ia, np.arange(nu), masked=masked)
+
+
+@pytest.mark.parametrize("list_batches", [True, False])
+def test_train_entry_point_with_device_side_batches(device, tmp_path, list_batches):
+    """python -m yelprecommendation_amd.train model_name=CDAE synthetic=... fast_loader=true: pipeline -> sparse
+    device store -> list (or dense) batches -> run() (train / validate / best model) -> evaluate(test)."""
+    from yelprecommendation_amd import train
+    metrics = train.main(["model_name=CDAE", "synthetic=300x900x14", "fast_loader=true", "epochs=3", "batch_size=64",
+                          "hidden_size=64", "device=cuda", f"model_dir={tmp_path}", "lr=0.01", "loss_name=bce",
+                          f"list_batches={'true' if list_batches else 'false'}"])
+    assert len(metrics) == 4 and all(np.isfinite(m) and 0.0 <= m <= 1.0 for m in metrics)
+    assert os.path.exists(os.path.join(str(tmp_path), "best_model.pt"))

@@ -117,8 +117,14 @@ def train(cfg, args):
         from .trainers.cdae_trainer import CDAETrainer
         if cfg.get("fast_loader"):
             from .data.cdae_batches import CDAEBatchLoader
+            # batches as lists straight from the per-user CSR (no dense rows or masks) when the fused step and the
+            # fused evaluation can take them: NS-BCE, Adam / AdamW, a hidden size the kernels are built for
+            as_lists = bool(cfg.get("list_batches", True)) and cfg.negative_sampling and cfg.get("fused_step", True) \
+                and cfg.optimizer.lower() in ("adam", "adamw") and cfg.hidden_size in (16, 32, 64, 128) \
+                and cfg.top_n <= 16 and args.cdae_data.num_items <= 245760
             mk = lambda mode, seed: CDAEBatchLoader(args.cdae_data, mode, cfg.batch_size, cfg.neg_times,
-                                                    shuffle=cfg.shuffle and mode != 'test', seed=seed)
+                                                    shuffle=cfg.shuffle and mode != 'test', seed=seed, lists=as_lists,
+                                                    dropout=cfg.corruption_level)
             train_dataloader, valid_dataloader, test_dataloader = mk('train', cfg.seed), mk('valid', cfg.seed + 1), mk('test', 0)
         else:
             test_dataloader = DataLoader(args.test_dataset, batch_size=cfg.batch_size)
