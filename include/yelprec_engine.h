@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 21
+#define YR_ENGINE_VERSION 22
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -204,6 +204,22 @@ int yr_bpr_mf_pull_apply(const float *U_old, float *U_new, float *I,
                          float *loss_partials, float *loss_out, double *loss_accum,
                          int phases, int64_t item_row_begin, int64_t item_row_end,
                          void *stream);
+/* yr_bpr_mf_pull_apply_ordered: the same with a start order for the item pass.  Its workgroups start in slot
+ * order and there are more item buckets (yr_bpr_mf_pull_item_buckets = ceil(num_items / (1024 / D))) than
+ * resident workgroups, so the last ones start when the first finish: item_bucket_order[slot] = bucket, a
+ * permutation of all item buckets with the heaviest (most occurrences per step) first, keeps the late starters
+ * short.  Popularity is a property of the data set, so one order (e.g. from the train set's item degrees) serves
+ * every step.  Results do not depend on it.  Ignored (as NULL) when the call covers only part of the item rows. */
+int yr_bpr_mf_pull_item_buckets(int64_t num_items, int D);
+int yr_bpr_mf_pull_apply_ordered(const float *U_old, float *U_new, float *I,
+                         float *mU, float *vU, float *mI, float *vI, float *gradI_out,
+                         int64_t B, int D, int64_t num_users, int64_t num_items, float inv_batch,
+                         double lr, double step_size, double bc2_sqrt,
+                         double beta1, double beta2, double eps, double weight_decay, int mode,
+                         int deterministic, void *workspace, int64_t workspace_bytes,
+                         float *loss_partials, float *loss_out, double *loss_accum,
+                         int phases, int64_t item_row_begin, int64_t item_row_end,
+                         const int32_t *item_bucket_order, void *stream);
 
 /* ---------------------------------------------------------------------------
  * NGCF message passing            (reference models/ngcf.py:60-72, embedding_propagation:

@@ -74,8 +74,14 @@ def test_deterministic_mode_is_bitwise_reproducible(device, shape):
         p = (torch.rand(B, generator=g, device=device).pow(2) * ni).long().clamp_(max=ni - 1)   # some long rows
         batches.append((u, p, torch.randint(0, ni, (B,), generator=g, device=device)))
     runs = []
-    for det in (True, True, False):
+    for run, det in enumerate((True, True, False)):
         st = BPRMFStep(U.clone(), I.clone(), lr=1e-3, deterministic=det, impl="pull")
+        # the start order of the item pass's workgroups (heaviest buckets first by default at large batches) is a
+        # scheduling matter only: run 0 keeps index order, run 1 takes a random permutation — still bit-identical
+        st.auto_item_order = False
+        if run == 1:
+            st.set_item_order(torch.rand(ni, generator=g, device=device))
+            assert st._item_order is not None and sorted(st._item_order.tolist()) == list(range(st._item_order.numel()))
         for k in range(steps):
             st.step(*batches[k % 5])
         st.check()

@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
-ENGINE_VERSION = 21
+ENGINE_VERSION = 22
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -65,6 +65,9 @@ SIGNATURES = {
     "yr_bpr_mf_pull_index": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _p, _p],
     "yr_bpr_mf_pull_apply": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _f,
                              _d, _d, _d, _d, _d, _d, _d, _int, _int, _p, _i64, _p, _p, _p, _int, _i64, _i64, _p],
+    "yr_bpr_mf_pull_apply_ordered": [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _int, _i64, _i64, _f,
+                             _d, _d, _d, _d, _d, _d, _d, _int, _int, _p, _i64, _p, _p, _p, _int, _i64, _i64, _p, _p],
+    "yr_bpr_mf_pull_item_buckets": [_i64, _int],
     "yr_loss_finalize": [_p, _f, _p, _p, _p],
     "yr_mf_scores_gemm": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _p, _p],
     "yr_mf_eval_topk_workspace_bytes": [_i64, _i64, _int],

@@ -78,6 +78,7 @@ class BPRMFStep:
             self._workspace(max_batch, 0)
         self._gI_dirty = False
         self._touched = None
+        self._item_order, self.auto_item_order = None, True
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.decoupled = optimizer.lower() == "adamw"
         self.world_size, self.pg = world_size, process_group
@@ -199,9 +200,33 @@ class BPRMFStep:
         # keep the tensors alive (and identify the batch) until the index is consumed
         self._indexed = (slot, (u, p, n))
 
+    def set_item_order(self, item_weight=None):
+        """Start order of the item pass's workgroups: buckets of 1024 / D item rows sorted by how many
+        occurrences they receive per step, heaviest first (``item_weight``: anything proportional to the items'
+        expected occurrences, e.g. the train set's item degrees + the uniform negatives' share; None: back to
+        index order).  There are more item buckets than resident workgroups, so the late starters should be the
+        light ones; results do not depend on the order."""
+        if item_weight is None:
+            self._item_order = None
+            return
+        nb = int(self._lib.yr_bpr_mf_pull_item_buckets(self.I.shape[0], self.I.shape[1]))
+        rows = -(-self.I.shape[0] // nb) if nb else 1
+        per = 1024 // self.I.shape[1]
+        w = torch.zeros(nb * per, dtype=torch.float64, device=self.I.device)
+        w[:self.I.shape[0]] = item_weight.to(self.I.device, torch.float64)
+        load = w.view(nb, per).sum(1)
+        self._item_order = torch.argsort(load, descending=True, stable=True).to(torch.int32).contiguous()
+
+    def _auto_item_order(self, p, n):
+        # first pull step: the batch's own occurrence counts stand for the data set's item popularity
+        counts = torch.bincount(p, minlength=self.I.shape[0]) + torch.bincount(n, minlength=self.I.shape[0])
+        self.set_item_order(counts[:self.I.shape[0]])
+
     def _step_pull(self, u, p, n, record, global_batch, next_batch=None):
         B = u.numel()
         D = self.U.shape[1]
+        if self._item_order is None and self.auto_item_order and B >= 4 * self.I.shape[0]:
+            self._auto_item_order(p, n)
         inv = 1.0 / global_batch if global_batch else 0.0
         self.t += 1
         multi = self.world_size > 1 or self.split_item_update
@@ -224,15 +249,17 @@ class BPRMFStep:
             if with_loss is None:
                 with_loss = bool(phases & engine.PULL_USER_PHASE)   # that call's last launch reduces the loss
             step_size, bc2_sqrt = engine.adam_scalars(self.t, self.lr, self.betas[0], self.betas[1])
-            rc = self._lib.yr_bpr_mf_pull_apply(
+            order = self._item_order
+            rc = self._lib.yr_bpr_mf_pull_apply_ordered(
                 self.U.data_ptr(), self._U_alt.data_ptr(), self._pI, self._pmU, self._pvU, self._pmI, self._pvI,
                 self.gI.data_ptr() if multi else None, B, D, self.U.shape[0], rows, inv, self.lr,
                 step_size, bc2_sqrt, self.betas[0], self.betas[1], self.eps, self.wd,
                 engine.OPT_ADAMW if self.decoupled else engine.OPT_ADAM, 1 if self.deterministic else 0,
                 ws.data_ptr(), ws.numel(), self._ppartials, ploss if with_loss else None,
-                paccum if with_loss else None, phases, r0, r1, engine._stream())
+                paccum if with_loss else None, phases, r0, r1, order.data_ptr() if order is not None else None,
+                engine._stream())
             if rc:
-                engine.check(rc, "yr_bpr_mf_pull_apply")
+                engine.check(rc, "yr_bpr_mf_pull_apply_ordered")
 
         def first_chunk():
             # lean host path (these calls are the whole step): index tensors are checked here, the

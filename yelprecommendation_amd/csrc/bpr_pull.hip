@@ -250,6 +250,7 @@ struct OwnerArgs {
   int nb, T, tile_stride;    // buckets on this side, tiles, records per tile region
   int rows;                  // rows of the own table
   int bucket_begin, bucket_end;
+  const int32_t* order;      // optional: workgroup slot -> bucket (a permutation of [0, nb): heaviest buckets first)
   int heavy_t;               // rows with more records in a chunk are walked by all four waves
   float inv_batch;
   AdamC adam;
@@ -443,7 +444,8 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
 #endif
   YR_STAMP(0);
 
-  for (int k = a.bucket_begin + blockIdx.x; k < a.bucket_end; k += gridDim.x) {
+  for (int ks = a.bucket_begin + blockIdx.x; ks < a.bucket_end; ks += gridDim.x) {
+    const int k = a.order ? a.order[ks] : ks;       // workgroups start in slot order: the caller may put heavy buckets first
     const int row_f = k * R + row_l;
     const bool valid_f = finisher && row_f < a.rows;
     const uint32_t o_f = (uint32_t)(row_f * D + 4 * l);
@@ -812,7 +814,8 @@ template <int D>
 static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU, float* vU, float* mI, float* vI,
                            float* gradI_out, int64_t B, int64_t nU, int64_t nI, float inv_batch, const AdamC& adam,
                            int deterministic, void* workspace, float* loss_partials, float* loss_out,
-                           double* loss_accum, int phases, int64_t item_begin, int64_t item_end, hipStream_t s) {
+                           double* loss_accum, int phases, int64_t item_begin, int64_t item_end,
+                           const int32_t* item_order, hipStream_t s) {
   const PullPlan p = make_plan(B, nU, nI, D, false);
   char* w = static_cast<char*>(workspace);
   const bool want_loss = loss_out || loss_accum;
@@ -823,6 +826,7 @@ static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU
     ua.loss_partials = loss_partials;
     ua.nb = p.nbU; ua.T = p.T; ua.tile_stride = p.tile; ua.rows = (int)nU;
     ua.bucket_begin = 0; ua.bucket_end = p.nbU;
+    ua.order = nullptr;
     ua.heavy_t = kHeavyRow; ua.inv_batch = inv_batch; ua.adam = adam;
     const int gu = p.nbU < YR_LOSS_PARTIALS ? p.nbU : YR_LOSS_PARTIALS;   // one loss-partial slot per workgroup
     if (p.narrow_users && deterministic)
@@ -844,6 +848,8 @@ static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU
     ia.nb = p.nbI; ia.T = p.T; ia.tile_stride = 2 * p.tile; ia.rows = (int)nI;
     ia.bucket_begin = (int)(item_begin >> p.shiftI);
     ia.bucket_end = (int)((item_end + (1 << p.shiftI) - 1) >> p.shiftI);
+    // a start order is a permutation of ALL item buckets: used when the call covers all of them
+    ia.order = (item_order && ia.bucket_begin == 0 && ia.bucket_end == p.nbI) ? item_order : nullptr;
     ia.heavy_t = kHeavyRow; ia.inv_batch = inv_batch; ia.adam = adam;
     int gi = ia.bucket_end - ia.bucket_begin;
     if (gi > kMaxOwnerGrid) gi = kMaxOwnerGrid;
@@ -862,13 +868,20 @@ static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU
   return launch_status();
 }
 
-extern "C" int yr_bpr_mf_pull_apply(const float* U_old, float* U_new, float* I, float* mU, float* vU, float* mI,
-                                    float* vI, float* gradI_out, int64_t B, int D, int64_t num_users,
-                                    int64_t num_items, float inv_batch, double lr, double step_size, double bc2_sqrt,
-                                    double beta1, double beta2, double eps, double weight_decay, int mode,
-                                    int deterministic, void* workspace, int64_t workspace_bytes,
-                                    float* loss_partials, float* loss_out, double* loss_accum, int phases,
-                                    int64_t item_row_begin, int64_t item_row_end, void* stream) {
+extern "C" int yr_bpr_mf_pull_item_buckets(int64_t num_items, int D) {
+  if (num_items <= 0 || (D != 16 && D != 32 && D != 64 && D != 128)) return YR_ERR_BADARG;
+  const int sh = bucket_shift(D);
+  return (int)((num_items + (1 << sh) - 1) >> sh);
+}
+
+extern "C" int yr_bpr_mf_pull_apply_ordered(const float* U_old, float* U_new, float* I, float* mU, float* vU,
+                                            float* mI, float* vI, float* gradI_out, int64_t B, int D,
+                                            int64_t num_users, int64_t num_items, float inv_batch, double lr,
+                                            double step_size, double bc2_sqrt, double beta1, double beta2, double eps,
+                                            double weight_decay, int mode, int deterministic, void* workspace,
+                                            int64_t workspace_bytes, float* loss_partials, float* loss_out,
+                                            double* loss_accum, int phases, int64_t item_row_begin,
+                                            int64_t item_row_end, const int32_t* item_bucket_order, void* stream) {
   int rc = pull_check_common(B, D, num_users, num_items, workspace, workspace_bytes);
   if (rc) return rc;
   if (!(phases & (YR_PULL_USER_PHASE | YR_PULL_ITEM_PHASE))) return YR_ERR_BADARG;
@@ -886,7 +899,7 @@ extern "C" int yr_bpr_mf_pull_apply(const float* U_old, float* U_new, float* I, 
   case DD:                                                                                                      \
     return pull_apply_impl<DD>(U_old, U_new, I, mU, vU, mI, vI, gradI_out, B, num_users, num_items, inv_batch,  \
                                c, deterministic ? 1 : 0, workspace, loss_partials, loss_out, loss_accum, phases,      \
-                               item_row_begin, item_row_end, s)
+                               item_row_begin, item_row_end, item_bucket_order, s)
   switch (D) {
     YR_APPLY_CASE(16);
     YR_APPLY_CASE(32);
@@ -895,6 +908,19 @@ extern "C" int yr_bpr_mf_pull_apply(const float* U_old, float* U_new, float* I, 
     default: return YR_ERR_UNSUPPORTED;
   }
 #undef YR_APPLY_CASE
+}
+
+extern "C" int yr_bpr_mf_pull_apply(const float* U_old, float* U_new, float* I, float* mU, float* vU, float* mI,
+                                    float* vI, float* gradI_out, int64_t B, int D, int64_t num_users,
+                                    int64_t num_items, float inv_batch, double lr, double step_size, double bc2_sqrt,
+                                    double beta1, double beta2, double eps, double weight_decay, int mode,
+                                    int deterministic, void* workspace, int64_t workspace_bytes,
+                                    float* loss_partials, float* loss_out, double* loss_accum, int phases,
+                                    int64_t item_row_begin, int64_t item_row_end, void* stream) {
+  return yr_bpr_mf_pull_apply_ordered(U_old, U_new, I, mU, vU, mI, vI, gradI_out, B, D, num_users, num_items,
+                                      inv_batch, lr, step_size, bc2_sqrt, beta1, beta2, eps, weight_decay, mode,
+                                      deterministic, workspace, workspace_bytes, loss_partials, loss_out, loss_accum,
+                                      phases, item_row_begin, item_row_end, nullptr, stream);
 }
 
 extern "C" int yr_bpr_mf_pull_step(const float* U_old, float* U_new, float* I, float* mU, float* vU, float* mI,
