@@ -62,9 +62,6 @@ constexpr int kMaxOwnerGrid = 4096;
 #ifndef YR_HEAVY_ROW
 #define YR_HEAVY_ROW 96
 #endif
-#ifndef YR_ROWSUM_REGS
-#define YR_ROWSUM_REGS 0             // 4: row sums of a wave's rows in registers when it owns at most four (D >= 64)
-#endif
 constexpr int kHeavyRow = YR_HEAVY_ROW;          // records per row and chunk from which all four waves share the row
 #ifndef YR_OWNER_WAVES
 #define YR_OWNER_WAVES 8              // waves per SIMD the owner pass is compiled for (8 workgroups per CU: <= 64 VGPRs)
@@ -278,56 +275,27 @@ __device__ __forceinline__ int wave_inclusive_scan(int x, int lane) {
   return x;
 }
 
-// Per lane group: the sums of the rows this WAVE owns (GPW rows, one per lane group at the end).  A
-// wave's stream is sorted by row, so a lane group sums into `cur` while its row stays the same and
-// books `cur` under the row when the row changes.  Up to four rows per wave (D >= 64): one
-// accumulator per row in registers, predicated adds, no cross-lane traffic until the bucket is
-// finished.  More rows per wave (D = 16, 32): the groups closing the same row combine with
-// shuffles and the owning group adds the result.
+// Per lane group: the sum of the row this group finishes (a wave owns GPW rows, one per lane group at the end).
+// A wave's stream is sorted by row, so a lane group sums into `cur` while its row stays the same; when the row
+// changes, the groups closing the same row combine with shuffles and the owning group adds the result.  (One
+// register accumulator per row with predicated adds — no cross-lane traffic until the bucket is finished — cost 12
+// more VGPRs and with them the eighth workgroup per CU: measured slower and removed.)
 template <int LPR, int GPW>
 struct RowSums {
-  static constexpr bool kRegs = GPW <= YR_ROWSUM_REGS;
-  float4 part[kRegs ? GPW : 1];
-  float4 total;                                   // running sum of this group's own row (generic form; heavy rows)
-  __device__ __forceinline__ void clear() {
-#pragma unroll
-    for (int j = 0; j < (kRegs ? GPW : 1); ++j) part[j] = zero4();
-    total = zero4();
-  }
+  float4 total;                                   // running sum of this group's own row
+  __device__ __forceinline__ void clear() { total = zero4(); }
   // `cur_row` = row index inside the wave (0..GPW-1)
   __device__ __forceinline__ void book(bool closing, int cur_row, const float4& cur, int grp) {
-    if (kRegs) {
-#pragma unroll
-      for (int j = 0; j < GPW; ++j) {
-        const bool s = closing && cur_row == j;
-        part[j].x += s ? cur.x : 0.0f; part[j].y += s ? cur.y : 0.0f;
-        part[j].z += s ? cur.z : 0.0f; part[j].w += s ? cur.w : 0.0f;
-      }
-    } else {
 #pragma unroll 1
-      for (int j = 0; j < GPW; ++j) {
-        const bool sel = closing && cur_row == j;
-        if (!__ballot(sel)) continue;               // wave-uniform
-        float4 v = sel ? cur : zero4();
-        cross_group_sum<LPR>(v);
-        if (grp == j) { total.x += v.x; total.y += v.y; total.z += v.z; total.w += v.w; }
-      }
+    for (int j = 0; j < GPW; ++j) {
+      const bool sel = closing && cur_row == j;
+      if (!__ballot(sel)) continue;               // wave-uniform
+      float4 v = sel ? cur : zero4();
+      cross_group_sum<LPR>(v);
+      if (grp == j) { total.x += v.x; total.y += v.y; total.z += v.z; total.w += v.w; }
     }
   }
-  // the sum of this lane group's own row
-  __device__ __forceinline__ float4 finish(int grp) {
-    if (kRegs) {
-      float4 out = total;
-#pragma unroll
-      for (int j = 0; j < GPW; ++j) {
-        float4 t = part[j];
-        cross_group_sum<LPR>(t);
-        if (grp == j) { out.x += t.x; out.y += t.y; out.z += t.z; out.w += t.w; }
-      }
-      return out;
-    }
-    return total;
-  }
+  __device__ __forceinline__ float4 finish(int) { return total; }
 };
 
 #ifndef YR_USER_UNROLL
@@ -445,7 +413,8 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
   YR_STAMP(0);
 
   for (int ks = a.bucket_begin + blockIdx.x; ks < a.bucket_end; ks += gridDim.x) {
-    const int k = a.order ? a.order[ks] : ks;       // workgroups start in slot order: the caller may put heavy buckets first
+    // workgroups start in slot order: the caller may put heavy buckets first (wave-uniform: kept in a scalar register)
+    const int k = __builtin_amdgcn_readfirstlane(a.order ? a.order[ks] : ks);
     const int row_f = k * R + row_l;
     const bool valid_f = finisher && row_f < a.rows;
     const uint32_t o_f = (uint32_t)(row_f * D + 4 * l);
