@@ -351,7 +351,7 @@ int yr_cdae_compact_pair(const float *x, const float *negative_mask, int64_t B, 
  *   buffers sized and laid out as for yr_cdae_compact_pair.  ptr2 / idx2 (may be NULL): a second CSR whose items
  *   are positives of the LOSS list as well (validation: target = train + held-out items, cdae_trainer.py:67) and
  *   count towards neg_times, but do not enter the encoder list.  err_flag: YR_FLAG_BAD_USER, YR_FLAG_BAD_ITEM (bad or
- *   repeated item id, or more negatives wanted than non-positives exist).  I <= 245,760. */
+ *   repeated item id, or more negatives wanted than non-positives exist).  I <= 245,760 (163,840 with ptr2). */
 int yr_cdae_train_lists(const int64_t *ptr, const int64_t *idx, const int64_t *ptr2, const int64_t *idx2,
                         const int64_t *users, int64_t B,
                         int64_t num_users, int64_t I, int neg_times, uint64_t neg_seed,

@@ -121,7 +121,7 @@ def train(cfg, args):
             # fused evaluation can take them: NS-BCE, Adam / AdamW, a hidden size the kernels are built for
             as_lists = bool(cfg.get("list_batches", True)) and cfg.negative_sampling and cfg.get("fused_step", True) \
                 and cfg.optimizer.lower() in ("adam", "adamw") and cfg.hidden_size in (16, 32, 64, 128) \
-                and cfg.top_n <= 16 and args.cdae_data.num_items <= 245760
+                and cfg.top_n <= 16 and args.cdae_data.num_items <= 163840
             mk = lambda mode, seed: CDAEBatchLoader(args.cdae_data, mode, cfg.batch_size, cfg.neg_times,
                                                     shuffle=cfg.shuffle and mode != 'test', seed=seed, lists=as_lists,
                                                     dropout=cfg.corruption_level)
