@@ -426,9 +426,11 @@ def test_adam_flat_equals_adam_dense(device):
             and float(G[3].abs().sum()) > 0.0                                        # clear modes 1, 2 / left alone
 
 
-@pytest.mark.parametrize("ni,negative_sampling,decoder", [(1501, True, "dense"), (1504, True, "sampled"),
-                                                          (1501, True, "sampled"), (1503, False, "dense")])
-def test_fused_step_equals_autograd_route(device, tmp_path, ni, negative_sampling, decoder):
+@pytest.mark.parametrize("ni,negative_sampling,decoder,H", [(1501, True, "dense", 128), (1504, True, "sampled", 128),
+                                                            (1501, True, "sampled", 128), (1503, False, "dense", 128),
+                                                            (1001, True, "sampled", 32), (1001, True, "sampled", 256),
+                                                            (1001, True, "dense", 100)])
+def test_fused_step_equals_autograd_route(device, tmp_path, ni, negative_sampling, decoder, H):
     """cdae_step.CDAEStep — dense decoder (loss in the GEMM epilogue, count-scaled gradient products) and sampled
     decoder (forward, loss and decoder gradients on the loss positions only), one Adam launch —
     against the autograd route (model + loss module + optimizer.step) over four steps from the same init, with
@@ -440,7 +442,7 @@ def test_fused_step_equals_autograd_route(device, tmp_path, ni, negative_samplin
     from yelprecommendation_amd.optim import Adam
     from yelprecommendation_amd.utils import make_config
     rs = np.random.RandomState(ni)
-    nu, H, B, steps = 90, 128, 40, 4
+    nu, B, steps = 90, 40, 4
     t = lambda a: torch.from_numpy(a).to(device)
     batches = []
     for _ in range(steps):
