@@ -248,6 +248,36 @@ def test_fused_eval_catalogue_slices_equal_one_slice(device, ni, expect_slices):
             assert not set(a[r].tolist()) & set(lists[r].tolist())
 
 
+@pytest.mark.parametrize("d", [16, 32, 64, 128])
+def test_fused_eval_with_item_bias(device, d):
+    """yr_mf_eval_topk_bias: scores U[u] . I[j] + bias[j] (the CDAE decoder before its sigmoid).  The bias is the
+    MFMA accumulator's initial value, so the kernel must equal the bias-free kernel on tables augmented by one
+    column ([u, 1] . [i, b]) — checked through the near-tie comparison against float64 scores — sliced and
+    unsliced forms identical, ragged sizes, masks, a bias large enough to reorder everything."""
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(100 + d)
+    nu, ni, n = 150, 4131, 131
+    U, I = _tables(rs, nu, ni, d)
+    bias = (rs.standard_normal(ni) * 0.5).astype(np.float32)
+    users = rs.randint(0, nu, size=n).astype(np.int64)
+    lists = [np.sort(rs.choice(ni, size=(0 if r % 5 == 0 else rs.randint(1, 70)), replace=False)) for r in range(n)]
+    ptr = np.zeros(n + 1, np.int64); ptr[1:] = np.cumsum([len(l) for l in lists])
+    idx = np.concatenate(lists).astype(np.int64)
+    t = lambda a: torch.from_numpy(a).to(device)
+    Ua, Ia = np.c_[U, np.ones(nu, np.float32)], np.c_[I, bias]              # the same scores as plain dot products
+    exact = Ua[users].astype(np.float64) @ Ia.astype(np.float64).T
+    for r in range(n):
+        exact[r, lists[r]] = -np.inf
+    for k in (4, 10, 16):
+        want = np.argsort(-exact, axis=1, kind="stable")[:, :k]
+        a = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, item_bias=t(bias)).cpu().numpy()
+        b = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, item_bias=t(bias), sliced=False).cpu().numpy()
+        np.testing.assert_array_equal(a, b)
+        assert_topk_equal_up_to_near_ties(a, want, Ua, Ia, users, lists)
+        plain = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k).cpu().numpy()
+        assert (plain != a).any()                                            # the bias matters
+
+
 def test_fused_eval_mask_value_paths_agree(device):
     """-FLT_MAX (the reference's value) takes the lazy masking path of the fused kernel, any other
     value rewrites the scores before selection; with a value below every real score both must give
