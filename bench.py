@@ -376,6 +376,9 @@ def main():
                    "users": num_users, "items": num_items, "interactions": nnz,
                    "train_triplets_per_epoch": n_train_global, "batch_per_gpu": int(local_B) if strong else B,
                    "global_batch": global_batch,
+                   # weak scaling keeps the per-GPU batch fixed, so at N > 1 a step spans more than one epoch of
+                   # this (fixed-size) data set: every rank's stream wraps over its shard's rows
+                   "global_batch_in_epochs": round(global_batch / n_train_global, 2),
                    "optimizer": "adam(dense)", "parallelism": f"user-shard x{world}" if world > 1 else "single",
                    "step_impl": step.impl, "data_gen_s": round(data_s, 1)},
         "roofline": roofline,
