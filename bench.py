@@ -153,7 +153,7 @@ def other_workload(args):
                     pred = model(users, x)
                     opt.zero_grad(); lossf(pred, x, neg).backward(); opt.step()
             else:
-                fused, k = CDAEStep(model, opt, True, decoder=form), [0]
+                fused, k = CDAEStep(model, opt, True, decoder=form, transposed_wh=True), [0]    # as CDAETrainer builds it
 
                 def step():
                     k[0] += 1

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 22
+#define YR_ENGINE_VERSION 23
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -558,6 +558,15 @@ int yr_cdae_sparse_dwh(const int32_t *cols, const float *vals, const int32_t *co
                        const float *dz, int64_t B, int64_t I, int H, float *dWh,
                        float *scratch_T, int32_t *claim, int32_t epoch, int32_t *touched, int32_t *n_touched,
                        void *stream);
+/* The same two pieces on a TRANSPOSED working copy of W_h ([I, H]; cdae_step.py keeps one during an epoch and
+ * writes it back at the end): yr_cdae_sparse_encode_t reads row `col` of WhT (H contiguous floats per non-zero);
+ * yr_cdae_sparse_dwh_t adds dz[b,:] * val into row `col` of dWhT (contiguous float atomics; zero on entry where
+ * unmarked) and sets touched_items[col] = 1 — no scratch, one launch. */
+int yr_cdae_sparse_encode_t(const int32_t *cols, const float *vals, const int32_t *count, const float *WhT,
+                            const float *bh, const float *V, const int64_t *user, int64_t B, int64_t I,
+                            int H, int64_t num_users, int act, float *z, int32_t *err_flag, void *stream);
+int yr_cdae_sparse_dwh_t(const int32_t *cols, const float *vals, const int32_t *count, const float *dz,
+                         int64_t B, int64_t I, int H, float *dWhT, uint8_t *touched_items, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Device-side BPR triplet stream   (reference train.py:76-77: DataLoader(MFDataset, shuffle=True);

@@ -38,7 +38,7 @@ def auto():
 if mode in ("both", "auto"):
     print("autograd route  %.4f ms" % timed(auto), flush=True)
 if mode in ("both", "fused", "dense", "sampled"):
-    step = CDAEStep(model, opt, decoder="auto" if mode in ("both", "fused") else mode)
+    step = CDAEStep(model, opt, decoder="auto" if mode in ("both", "fused") else mode, transposed_wh=os.environ.get("YR_WHT", "1") == "1")
     print("decoder", step.decoder)
     k = [0]
 

@@ -434,7 +434,8 @@ def test_fused_step_equals_autograd_route(device, tmp_path, ni, negative_samplin
     """cdae_step.CDAEStep — dense decoder (loss in the GEMM epilogue, count-scaled gradient products) and sampled
     decoder (forward, loss and decoder gradients on the loss positions only), one Adam launch —
     against the autograd route (model + loss module + optimizer.step) over four steps from the same init, with
-    the same dropout seeds: losses, all parameters, all Adam moments.  Ragged catalogue widths, duplicate users,
+    the same dropout seeds: losses, all parameters, all Adam moments.  Odd catalogue widths run with the transposed
+    working copy of W_h (released and re-acquired in the middle of the run).  Ragged catalogue widths, duplicate users,
     an all-zero row; NS-BCE and plain BCE; then both against the NumPy oracle for the first step."""
     from yelprecommendation_amd.cdae_step import CDAEStep
     from yelprecommendation_amd.loss import BCELoss, NSBCELoss
@@ -458,13 +459,16 @@ def test_fused_step_equals_autograd_route(device, tmp_path, ni, negative_samplin
         opt = Adam(model.parameters(), lr=1e-3)
         losses = []
         if fused:
-            step = CDAEStep(model, opt, negative_sampling, decoder=decoder)
+            step = CDAEStep(model, opt, negative_sampling, decoder=decoder, transposed_wh=ni % 2 == 1)
             assert step.decoder == decoder
-            for u, x, neg, seed in batches:
+            for k, (u, x, neg, seed) in enumerate(batches):
                 step.step(t(u), t(x), t(neg) if negative_sampling else None, seed=seed, p=model.corruption_level)
                 losses.append(float(step.last_loss()))
+                if k == 1:
+                    step.release()                              # back to the module mid-run, re-acquired by the next step
+            step.release()
             assert abs(step.epoch_loss() - sum(losses)) < 1e-5 and float(step.dV.abs().sum()) == 0.0 \
-                and float(step.dWh.abs().sum()) == 0.0
+                and (step.dWh is None or float(step.dWh.abs().sum()) == 0.0)
             if decoder == "sampled":                                  # consumed gradients are cleared, marks reset
                 assert float(step.dWo.abs().sum()) == 0.0 and float(step.dbo.abs().sum()) == 0.0
             step.check()
@@ -491,8 +495,9 @@ def test_fused_step_equals_autograd_route(device, tmp_path, ni, negative_samplin
     u, x, neg, seed = batches[0]
     xin = engine_dropout(t(x), seed, model.corruption_level).cpu().numpy()
     want = float(ref.train_step(u, xin, x, neg if negative_sampling else np.ones_like(x)))
-    step = CDAEStep(model, Adam(model.parameters(), lr=1e-3), negative_sampling, decoder=decoder)
+    step = CDAEStep(model, Adam(model.parameters(), lr=1e-3), negative_sampling, decoder=decoder, transposed_wh=ni % 2 == 1)
     step.step(t(u), t(x), t(neg) if negative_sampling else None, seed=seed, p=model.corruption_level)
+    step.release()
     np.testing.assert_allclose(float(step.last_loss()), want, rtol=1e-5)
     for p, r in zip(model.parameters(), ref.params):
         np.testing.assert_allclose(p.detach().cpu().numpy(), r, rtol=1e-3, atol=2e-6)

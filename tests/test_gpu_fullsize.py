@@ -146,8 +146,9 @@ def test_cdae_full_size_step_matches_oracle(device, tmp_path):
     for decoder in ("sampled", "dense"):
         torch.manual_seed(2)
         model2 = CDAE(cfg, NI, NU)
-        step = CDAEStep(model2, Adam(model2.parameters(), lr=1e-3), decoder=decoder)
+        step = CDAEStep(model2, Adam(model2.parameters(), lr=1e-3), decoder=decoder, transposed_wh=decoder == "sampled")
         step.step(t(u), t(x), t(neg), x_in=t(xin))
+        step.release()
         np.testing.assert_allclose(float(step.last_loss()), want, rtol=1e-5)
         for (name, p), r in zip(model2.named_parameters(), ref.params):
             np.testing.assert_allclose(p.detach().cpu().numpy(), r, rtol=1e-3, atol=2e-6, err_msg=f"{decoder} {name}")

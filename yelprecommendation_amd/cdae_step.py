@@ -18,7 +18,8 @@ without materialising ``pred`` or the loss gradient w.r.t. it:
     9  Adam / AdamW on all five parameters                                       yr_adam_dense_flat
 
 Eleven launches (8 is a memset and two kernels) against ~26 through autograd, and 5 passes over [B, I]
-data instead of 11.
+data instead of 11.  With ``transposed_wh`` (what CDAETrainer uses) steps 2 and 8 work on an [I, H] working copy of
+W_h: 8 becomes one launch (yr_cdae_sparse_dwh_t), 2 reads one 512-byte row per input item.
 
 With NS-BCE the loss reads the prediction on the positions where target + negative_mask != 0 only (loss.py:14-16)
 — (1 + neg_times) x the positives of a row, a fraction of a percent of the catalogue — and its gradient w.r.t.
@@ -37,10 +38,17 @@ from . import engine
 
 
 class CDAEStep:
-    def __init__(self, model, optimizer, negative_sampling=True, decoder="auto"):
+    def __init__(self, model, optimizer, negative_sampling=True, decoder="auto", transposed_wh=False):
         """``decoder``: "sampled" — forward, loss and the three decoder gradients on the loss positions only
         (NS-BCE reads nothing else; needs a negative mask), "dense" — the full-catalogue products on the matrix
-        cores, "auto" — sampled when the loss is NS-BCE and the hidden size allows it."""
+        cores, "auto" — sampled when the loss is NS-BCE and the hidden size allows it.
+        ``transposed_wh``: between ``acquire()`` (implicit in the first step) and ``release()`` the step trains a
+        TRANSPOSED working copy of W_h and of its two Adam moments ([I, H]): an input item is then a 512-byte row
+        for the encoder and for dW_h (contiguous float atomics straight into the gradient, no scratch, one launch),
+        and the Adam launch reads / clears the gradient rows of the batch's items only.  Adam is element-wise, so
+        the layout changes nothing in the arithmetic; ``release()`` writes the three tensors back — the caller must
+        do that before anything else reads ``hidden_layer.weight`` or the optimizer state (CDAETrainer.train does,
+        at the end of the epoch)."""
         from . import optim
         if not isinstance(optimizer, optim.Adam):
             raise NotImplementedError("CDAEStep: optimizer adam or adamw")
@@ -59,10 +67,13 @@ class CDAEStep:
         if decoder not in ("sampled", "dense") or (decoder == "sampled" and not can_sample):
             raise NotImplementedError(f"CDAEStep: decoder {decoder!r} with negative_sampling={negative_sampling}, H={H}")
         self.decoder = decoder
+        self.transposed_wh = bool(transposed_wh) and self.row_marks
+        self._wht = None                               # (WhT, mT, vT, dWhT, item marks) while acquired
         dev = self.params[0].device
         Wh, bh, V, Wo, bo = (p.data for p in self.params)
         f32 = torch.float32
-        self.dWh, self.dV = torch.zeros_like(Wh), torch.zeros_like(V)          # all-zero between steps
+        self.dV = torch.zeros_like(V)                                          # all-zero between steps, like
+        self.dWh = None if self.transposed_wh else torch.zeros_like(Wh)        # dW_h (or its transposed form)
         self.dbh = torch.empty_like(bh)
         if decoder == "sampled":                                                # accumulated into: zero between steps
             self.dWo, self.dbo = torch.zeros_like(Wo), torch.zeros_like(bo)
@@ -87,6 +98,29 @@ class CDAEStep:
         ps = [model.hidden_layer.weight, model.hidden_layer.bias, model.user_nodes.weight,
               model.output_layer.weight, model.output_layer.bias]
         return all(a is b for a, b in zip(ps, self.params)) and all("exp_avg" in optimizer.state[p] for p in ps)
+
+    def acquire(self):
+        """Take W_h and its Adam moments into the transposed working layout (no-op when already there)."""
+        if not self.transposed_wh or self._wht is not None:
+            return
+        Wh = self.params[0]
+        st = self.optimizer.state[Wh]
+        dev = Wh.device
+        self._wht = (Wh.data.t().contiguous(), st["exp_avg"].t().contiguous(), st["exp_avg_sq"].t().contiguous(),
+                     torch.zeros(Wh.shape[1], Wh.shape[0], dtype=torch.float32, device=dev),
+                     torch.zeros(Wh.shape[1], dtype=torch.uint8, device=dev))
+
+    def release(self):
+        """Write the working copy back into ``hidden_layer.weight`` and the optimizer's moments."""
+        if self._wht is None:
+            return
+        Wh = self.params[0]
+        st = self.optimizer.state[Wh]
+        WhT, mT, vT, _, _ = self._wht
+        Wh.data.copy_(WhT.t())
+        st["exp_avg"].copy_(mT.t())
+        st["exp_avg_sq"].copy_(vT.t())
+        self._wht = None
 
     def _buffers(self, B):
         if self._batch != B:
@@ -156,7 +190,13 @@ class CDAEStep:
         model = self.model
         Wh, bh, V, Wo, bo = (q.data for q in self.params)
         sampled = loss_lists is not None
-        engine.cdae_sparse_encode(rows, Wh, bh, V, user_id, model._hidden_act, err_flag=self.flag, out=self.z)
+        self.acquire()
+        wt = self._wht
+        if wt is not None:
+            engine.cdae_sparse_encode(rows, wt[0], bh, V, user_id, model._hidden_act, err_flag=self.flag, out=self.z,
+                                      transposed=True)
+        else:
+            engine.cdae_sparse_encode(rows, Wh, bh, V, user_id, model._hidden_act, err_flag=self.flag, out=self.z)
         self._blob.zero_()
         if sampled:
             engine.cdae_sampled_decode(loss_lists, self.z, Wo, bo, model._output_act, self.dz, self.dWo,
@@ -169,7 +209,10 @@ class CDAEStep:
         engine.cdae_hidden_bwd(self.dz, self.z, model._hidden_act, user_id, self.dV, self.touched_users, self.dbh,
                                self.partials, self.n_partials, self.count, self.stats, self.loss_accum,
                                scale_dz=sampled)
-        engine.cdae_sparse_dwh(rows, self.dz, self.dWh)
+        if wt is not None:
+            engine.cdae_sparse_dwh_t(rows, self.dz, wt[3], wt[4])
+        else:
+            engine.cdae_sparse_dwh(rows, self.dz, self.dWh)
         group = self.optimizer.param_groups[0]
         st = [self.optimizer.state[q] for q in self.params]
         t = int(st[0]["step"]) + 1
@@ -177,9 +220,11 @@ class CDAEStep:
         marks = (None, None, self.touched_users, None, None)
         clear = (1, 0, int(self.touched_users is None), 2 if sampled else 0, int(sampled))
         scaled = (False, False, False, sampled, sampled)
-        engine.adam_dense_flat([(q.data, g, s["exp_avg"], s["exp_avg_sq"], m, c, sc)
-                                for q, g, s, m, c, sc in zip(self.params, grads, st, marks, clear, scaled)],
-                               t, group["lr"], group["betas"][0], group["betas"][1], group["eps"],
+        tensors = [(q.data, g, s["exp_avg"], s["exp_avg_sq"], m, c, sc)
+                   for q, g, s, m, c, sc in list(zip(self.params, grads, st, marks, clear, scaled))[1 if wt is not None else 0:]]
+        if wt is not None:                             # W_h: the working copy, gradient rows by item mark
+            tensors.insert(0, (wt[0], wt[3], wt[1], wt[2], wt[4], 0, False))
+        engine.adam_dense_flat(tensors, t, group["lr"], group["betas"][0], group["betas"][1], group["eps"],
                                group["weight_decay"], decoupled=self.optimizer._decoupled,
                                grad_count=self.count if sampled else None)
         for s in st:

@@ -147,7 +147,11 @@ __device__ __forceinline__ int gather_row_list(const int32_t* __restrict__ cols,
   return n;
 }
 
-// one workgroup per row, one thread per hidden unit (looped when H > 256)
+// one workgroup per row, one thread per hidden unit (looped when H > 256).  WT: W_h is given TRANSPOSED, [I, H]
+// (the working copy cdae_step.py keeps during an epoch): the 'column' of an entry is then H contiguous floats —
+// one 512-byte line per entry and workgroup instead of one line per entry and THREAD (44 MB of fetches for ~3,000
+// entries per batch in the [H, I] layout).
+template <bool WT>
 __global__ __launch_bounds__(kBlock) void cdae_sparse_encode_kernel(
     const int32_t* __restrict__ cols, const float* __restrict__ vals, const int32_t* __restrict__ count, int64_t cpp,
     const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ V,
@@ -162,18 +166,20 @@ __global__ __launch_bounds__(kBlock) void cdae_sparse_encode_kernel(
   if (!ok && threadIdx.x == 0 && err_flag) atomicOr(err_flag, YR_FLAG_BAD_USER);
   for (int h0 = 0; h0 < H; h0 += kBlock) {           // H <= 256: one round
     const int h = h0 + threadIdx.x;
-    const float* wrow = Wh + (int64_t)min(h, H - 1) * I;
+    const int hc = min(h, H - 1);
+    const float* wrow = WT ? Wh + hc : Wh + (int64_t)hc * I;      // element of column c: wrow[c * pitch]
+    const int64_t pitch = WT ? H : 1;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     for (int skip = 0;; skip += kListCap) {
       const int n = gather_row_list(cols, vals, count, cpp, r, skip, s_pre, s_col, s_val);
       int j = 0;
       for (; j + 4 <= n; j += 4) {
-        acc0 = fmaf(s_val[j], wrow[s_col[j]], acc0);
-        acc1 = fmaf(s_val[j + 1], wrow[s_col[j + 1]], acc1);
-        acc2 = fmaf(s_val[j + 2], wrow[s_col[j + 2]], acc2);
-        acc3 = fmaf(s_val[j + 3], wrow[s_col[j + 3]], acc3);
+        acc0 = fmaf(s_val[j], wrow[s_col[j] * pitch], acc0);
+        acc1 = fmaf(s_val[j + 1], wrow[s_col[j + 1] * pitch], acc1);
+        acc2 = fmaf(s_val[j + 2], wrow[s_col[j + 2] * pitch], acc2);
+        acc3 = fmaf(s_val[j + 3], wrow[s_col[j + 3] * pitch], acc3);
       }
-      for (; j < n; ++j) acc0 = fmaf(s_val[j], wrow[s_col[j]], acc0);
+      for (; j < n; ++j) acc0 = fmaf(s_val[j], wrow[s_col[j] * pitch], acc0);
       const bool more = skip + n < s_pre[kParts];
       __syncthreads();                               // the staged list is overwritten by the next round
       if (!more) break;
@@ -228,6 +234,29 @@ __global__ __launch_bounds__(kBlock) void cdae_sparse_dwh_scatter_kernel(const i
       dWh[(int64_t)h * I + col] = *t;                 // dWh is zero on entry: a store, not a strided read-modify-write
       *t = 0.0f;
     }
+  }
+}
+
+// dW_h when the gradient is kept transposed ([I, H], beside the transposed working copy of W_h): the H-vector of
+// every non-zero goes straight into row `col` with contiguous float atomics and the row is marked for the Adam
+// launch (which reads and clears marked rows only) — no scratch, no claim words, no second launch.
+__global__ __launch_bounds__(kBlock) void cdae_sparse_dwh_t_kernel(
+    const int32_t* __restrict__ cols, const float* __restrict__ vals, const int32_t* __restrict__ count, int64_t cpp,
+    const float* __restrict__ dz, int H, float* __restrict__ dWhT, uint8_t* __restrict__ touched_items) {
+  __shared__ int s_pre[kParts + 1];
+  __shared__ int32_t s_col[kListCap];
+  __shared__ float s_val[kListCap];
+  const int64_t r = blockIdx.x;
+  for (int skip = 0;; skip += kListCap) {
+    const int n = gather_row_list(cols, vals, count, cpp, r, skip, s_pre, s_col, s_val);
+    for (int j = threadIdx.x; j < n; j += kBlock) touched_items[s_col[j]] = 1;
+    for (int h = threadIdx.x; h < H; h += kBlock) {
+      const float g = dz[r * H + h];
+      for (int j = 0; j < n; ++j) atomicAdd(dWhT + (int64_t)s_col[j] * H + h, g * s_val[j]);
+    }
+    const bool more = skip + n < s_pre[kParts];
+    __syncthreads();
+    if (!more) break;
   }
 }
 
@@ -392,8 +421,29 @@ extern "C" int yr_cdae_sparse_encode(const int32_t* cols, const float* vals, con
   if (B < 0 || I <= 0 || H <= 0 || num_users <= 0 || (act != 0 && act != 1)) return YR_ERR_BADARG;
   if (B == 0) return 0;
   if (!cols || !vals || !count || !Wh || !bh || !V || !user || !z) return YR_ERR_BADARG;
-  hipLaunchKernelGGL(cdae_sparse_encode_kernel, dim3((unsigned)B), dim3(kBlock), 0, (hipStream_t)stream, cols, vals,
-                     count, yr_cdae_sparse_part_columns(I), Wh, bh, V, user, I, H, num_users, act, z, err_flag);
+  hipLaunchKernelGGL((cdae_sparse_encode_kernel<false>), dim3((unsigned)B), dim3(kBlock), 0, (hipStream_t)stream, cols,
+                     vals, count, yr_cdae_sparse_part_columns(I), Wh, bh, V, user, I, H, num_users, act, z, err_flag);
+  return launch_status();
+}
+
+extern "C" int yr_cdae_sparse_encode_t(const int32_t* cols, const float* vals, const int32_t* count, const float* WhT,
+                                       const float* bh, const float* V, const int64_t* user, int64_t B, int64_t I,
+                                       int H, int64_t num_users, int act, float* z, int32_t* err_flag, void* stream) {
+  if (B < 0 || I <= 0 || H <= 0 || num_users <= 0 || (act != 0 && act != 1)) return YR_ERR_BADARG;
+  if (B == 0) return 0;
+  if (!cols || !vals || !count || !WhT || !bh || !V || !user || !z) return YR_ERR_BADARG;
+  hipLaunchKernelGGL((cdae_sparse_encode_kernel<true>), dim3((unsigned)B), dim3(kBlock), 0, (hipStream_t)stream, cols,
+                     vals, count, yr_cdae_sparse_part_columns(I), WhT, bh, V, user, I, H, num_users, act, z, err_flag);
+  return launch_status();
+}
+
+extern "C" int yr_cdae_sparse_dwh_t(const int32_t* cols, const float* vals, const int32_t* count, const float* dz,
+                                    int64_t B, int64_t I, int H, float* dWhT, uint8_t* touched_items, void* stream) {
+  if (B < 0 || I <= 0 || H <= 0) return YR_ERR_BADARG;
+  if (B == 0) return 0;
+  if (!cols || !vals || !count || !dz || !dWhT || !touched_items) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(cdae_sparse_dwh_t_kernel, dim3((unsigned)B), dim3(kBlock), 0, (hipStream_t)stream, cols, vals,
+                     count, yr_cdae_sparse_part_columns(I), dz, H, dWhT, touched_items);
   return launch_status();
 }
 

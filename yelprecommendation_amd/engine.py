@@ -562,17 +562,28 @@ class SparseRows:
         return torch.cat([c[q, :int(n[q])] for q in range(SPARSE_PARTS)])
 
 
-def cdae_sparse_encode(rows: "SparseRows", Wh, bh, V, user, act, err_flag=None, out=None):
-    """z = act(Wh . rows + bh + V[user])   (reference models/cdae.py:49, sparse input)."""
+def cdae_sparse_encode(rows: "SparseRows", Wh, bh, V, user, act, err_flag=None, out=None, transposed=False):
+    """z = act(Wh . rows + bh + V[user])   (reference models/cdae.py:49, sparse input).  ``transposed``: ``Wh`` is the
+    [I, H] working copy (yr_cdae_sparse_encode_t)."""
     lib = _lib.load()
-    H = Wh.shape[0]
+    H = Wh.shape[1] if transposed else Wh.shape[0]
     z = torch.empty(rows.B, H, dtype=torch.float32, device=Wh.device) if out is None else out
-    check(lib.yr_cdae_sparse_encode(rows.cols.data_ptr(), rows.vals.data_ptr(), rows.count.data_ptr(),
+    fn = lib.yr_cdae_sparse_encode_t if transposed else lib.yr_cdae_sparse_encode
+    check(fn(rows.cols.data_ptr(), rows.vals.data_ptr(), rows.count.data_ptr(),
                                     _dev(Wh, torch.float32, "Wh"), _dev(bh, torch.float32, "bh"),
                                     _dev(V, torch.float32, "V"), _dev(user, torch.int64, "user"), rows.B, rows.I, H,
                                     V.shape[0], int(act), z.data_ptr(), _opt(err_flag, torch.int32, "err_flag"),
                                     _stream()), "yr_cdae_sparse_encode")
     return z
+
+
+def cdae_sparse_dwh_t(rows: "SparseRows", dz, dWhT, touched_items):
+    """dWhT [I, H] (zero where unmarked) += rows^T . dz, rows marked in ``touched_items`` (yr_cdae_sparse_dwh_t)."""
+    lib = _lib.load()
+    check(lib.yr_cdae_sparse_dwh_t(rows.cols.data_ptr(), rows.vals.data_ptr(), rows.count.data_ptr(),
+                                   _dev(dz, torch.float32, "dz"), rows.B, rows.I, dz.shape[1],
+                                   _dev(dWhT, torch.float32, "dWhT"), _dev(touched_items, torch.uint8, "touched_items"),
+                                   _stream()), "yr_cdae_sparse_dwh_t")
 
 
 _dwh_scratch = {}

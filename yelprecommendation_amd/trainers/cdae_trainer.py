@@ -57,7 +57,8 @@ class CDAETrainer(BaseTrainer):
             return None
         if self._step is None or not self._step.bound_to(self.model, self.optimizer):
             self._step = CDAEStep(self.model, self.optimizer, self.cfg.negative_sampling,
-                                  decoder=self.cfg.get("train_decoder", "auto"))
+                                  decoder=self.cfg.get("train_decoder", "auto"),
+                                  transposed_wh=self.cfg.get("transposed_wh", True))
         return self._step
 
     def train(self, train_dataloader) -> float:
@@ -65,22 +66,11 @@ class CDAETrainer(BaseTrainer):
         self.model.train()
         step = self._fused_step()
         if step is not None:
-            model = self.model
-            own_noise = "add_noise" not in model.__dict__ and type(model).add_noise is CDAE.add_noise
             step.loss_accum.zero_()
-            for data in train_dataloader:
-                if 'lists' in data:                        # data/cdae_batches.py CDAEBatchLoader(lists=True)
-                    step.step_lists(data['user_id'].to(self.device), data['lists'])
-                    continue
-                user_id, input_mask = data['user_id'].to(self.device), data['input_mask'].to(self.device)
-                negative_mask = data['negative_mask'].to(self.device) if self.cfg.negative_sampling else None
-                if own_noise:
-                    # the seed draw of CDAE.forward (same position in torch's generator stream)
-                    p = model.corruption_level
-                    seed = int(torch.randint(0, 1 << 62, (1,)).item()) if p > 0 else 0
-                    step.step(user_id, input_mask, negative_mask, seed=seed, p=p)
-                else:                                       # an overridden add_noise (tests replay recorded masks)
-                    step.step(user_id, input_mask, negative_mask, x_in=model.add_noise(input_mask))
+            try:
+                self._train_fused(step, train_dataloader)
+            finally:
+                step.release()                             # W_h and its moments back into the module / optimizer
             step.check()
             return step.epoch_loss()
         self._loss_accum.zero_()
@@ -98,6 +88,23 @@ class CDAETrainer(BaseTrainer):
             self._accumulate(loss)
         self.model.check_indices()
         return float(self._loss_accum.item())
+
+    def _train_fused(self, step, train_dataloader):
+        model = self.model
+        own_noise = "add_noise" not in model.__dict__ and type(model).add_noise is CDAE.add_noise
+        for data in train_dataloader:
+            if 'lists' in data:                            # data/cdae_batches.py CDAEBatchLoader(lists=True)
+                step.step_lists(data['user_id'].to(self.device), data['lists'])
+                continue
+            user_id, input_mask = data['user_id'].to(self.device), data['input_mask'].to(self.device)
+            negative_mask = data['negative_mask'].to(self.device) if self.cfg.negative_sampling else None
+            if own_noise:
+                # the seed draw of CDAE.forward (same position in torch's generator stream)
+                p = model.corruption_level
+                seed = int(torch.randint(0, 1 << 62, (1,)).item()) if p > 0 else 0
+                step.step(user_id, input_mask, negative_mask, seed=seed, p=p)
+            else:                                           # an overridden add_noise (tests replay recorded masks)
+                step.step(user_id, input_mask, negative_mask, x_in=model.add_noise(input_mask))
 
     def _scored_by_lists(self, dataloader, with_loss):
         """validate / evaluate over list batches (CDAEBatchLoader(lists=True)): per batch only the encoder runs
