@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 23
+#define YR_ENGINE_VERSION 24
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -333,7 +333,7 @@ int yr_cdae_hidden_bwd(float *dz, const float *z, int act, const int64_t *user, 
  *   pass over x and negative_mask, the loss positions of every row as (column, target) lists in the same
  *   32-sub-list layout (loss_cols / loss_targets / loss_count sized like cols / vals / count).
  * yr_cdae_sampled_decode: per position (b, i): y = act(z[b] . W_o[i] + b_o[i]), its BCE term (clamped at -100)
- *   into partial_loss[b * yr_cdae_sampled_decode_splits() + s] (fixed order), g = (y - t) / max((1 - y) y,
+ *   into partial_loss[b * yr_cdae_sampled_decode_splits(B) + s] (fixed order), g = (y - t) / max((1 - y) y,
  *   1e-12) * act'(y), then dz[b,:] += g W_o[i,:] (dz zero on entry), dW_o[i,:] += g z[b,:], db_o[i] += g
  *   (float atomics; both buffers zero on entry), count (spread,
  *   YR_COUNT_WORDS, zero on entry) += positions.  Nothing carries the 1 / count of the mean: the consumers apply
@@ -358,7 +358,7 @@ int yr_cdae_train_lists(const int64_t *ptr, const int64_t *idx, const int64_t *p
                         uint64_t drop_seed, double p, int32_t *cols, float *vals, int32_t *count,
                         int32_t *loss_cols, float *loss_targets, int32_t *loss_count,
                         int32_t *err_flag, void *stream);
-int yr_cdae_sampled_decode_splits(void);
+int yr_cdae_sampled_decode_splits(int64_t B);
 /* yr_cdae_sampled_decode with dz = dWo = dbo = NULL computes the loss partials and the count only (validation);
  * yr_cdae_loss_finalize then gives stats[0] = sum(partials) / count (fixed order), stats[1] = count,
  * *loss_accum += stats[0] (may be NULL). */

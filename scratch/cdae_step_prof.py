@@ -9,7 +9,7 @@ from yelprecommendation_amd.optim import Adam
 from yelprecommendation_amd.utils import make_config
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "both"
-NU, NI, B, H = 31668, 38048, 256, 128
+NU, NI, B, H = 31668, 38048, int(os.environ.get('YR_B', '256')), 128
 dev = torch.device("cuda")
 model = CDAE(make_config("CDAE", hidden_size=H, device="cuda", model_dir="/tmp/yr_bench", lr=1e-4), NI, NU)
 opt, lossf = Adam(model.parameters(), lr=1e-4), NSBCELoss()

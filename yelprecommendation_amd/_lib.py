@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
-ENGINE_VERSION = 23
+ENGINE_VERSION = 24
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -51,7 +51,7 @@ SIGNATURES = {
     "yr_cdae_train_lists": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _int, C.c_uint64, C.c_uint64, _d, _p, _p, _p, _p, _p,
                             _p, _p, _p],
     "yr_cdae_loss_finalize": [_p, _i64, _p, _p, _p, _p],
-    "yr_cdae_sampled_decode_splits": [],
+    "yr_cdae_sampled_decode_splits": [_i64],
     "yr_cdae_sampled_decode": [_p, _p, _p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p, _p, _p, _p, _p],
     "yr_cdae_hidden_init": [_p, _p, _p, _p, _i64, _int, _i64, _p, _p],
     "yr_dropout": [_p, _p, _d, _i64, _p, _p],

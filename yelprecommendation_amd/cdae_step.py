@@ -135,7 +135,7 @@ class CDAEStep:
             self.row_count = torch.empty(B * engine.SPARSE_PARTS, dtype=torch.int32, device=dev)
             self.loss_lists = None                        # made on the first dense batch (step_lists brings its own)
             if self.decoder == "sampled":
-                self.n_partials = B * engine.cdae_sampled_decode_splits()
+                self.n_partials = B * engine.cdae_sampled_decode_splits(B)
             else:
                 ldg = (I + 3) // 4 * 4                                            # 16-byte rows: the gradient products
                 self.G = torch.empty(B, ldg, dtype=f32, device=dev)[:, :I]       # that read G take the tiled kernel

@@ -479,7 +479,13 @@ extern "C" int yr_cdae_compact_pair(const float* x, const float* negative_mask, 
   return launch_status();
 }
 
-extern "C" int yr_cdae_sampled_decode_splits(void) { return 2; }
+// workgroups per row: enough of them to fill the chip at small batches (at 256 rows 1 ... 8 splits measured equal:
+// the kernel then runs at the rate of its float atomics)
+extern "C" int yr_cdae_sampled_decode_splits(int64_t B) {
+  if (B <= 0) return 1;
+  const int64_t s = 512 / B;
+  return (int)(s < 1 ? 1 : s > 8 ? 8 : s);
+}
 
 extern "C" int yr_cdae_sampled_decode(const int32_t* loss_cols, const float* loss_targets, const int32_t* loss_count,
                                       const float* z, const float* Wo, const float* bo, int64_t B, int64_t I, int H,
@@ -491,7 +497,7 @@ extern "C" int yr_cdae_sampled_decode(const int32_t* loss_cols, const float* los
   if (!loss_cols || !loss_targets || !loss_count || !z || !Wo || !partial_loss || !count) return YR_ERR_BADARG;
   if ((dz || dWo || dbo) && !(dz && dWo && dbo)) return YR_ERR_BADARG;      // all three gradients or none
   if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(Wo)) & 15) return YR_ERR_BADARG;
-  const int splits = yr_cdae_sampled_decode_splits();
+  const int splits = yr_cdae_sampled_decode_splits(B);
   const int64_t cpp = yr_cdae_sparse_part_columns(I);
   const dim3 grid((unsigned)B, (unsigned)splits);
   hipStream_t s = (hipStream_t)stream;

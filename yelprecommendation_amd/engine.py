@@ -431,8 +431,8 @@ class TrainLists:
         return (t == 2.0).float(), (t == 1.0).float()
 
 
-def cdae_sampled_decode_splits():
-    return int(_lib.load().yr_cdae_sampled_decode_splits())
+def cdae_sampled_decode_splits(B):
+    return int(_lib.load().yr_cdae_sampled_decode_splits(int(B)))
 
 
 def cdae_sampled_decode(loss_lists, z, Wo, bo, act, dz, dWo, dbo, partial_loss, count):
@@ -444,7 +444,7 @@ def cdae_sampled_decode(loss_lists, z, Wo, bo, act, dz, dWo, dbo, partial_loss, 
     lc, lv, ln = loss_lists
     B, H = z.shape
     I = Wo.shape[0]
-    if partial_loss.numel() < B * cdae_sampled_decode_splits() or count.numel() != COUNT_WORDS:
+    if partial_loss.numel() < B * cdae_sampled_decode_splits(B) or count.numel() != COUNT_WORDS:
         raise EngineError("bad buffers for cdae_sampled_decode")
     check(lib.yr_cdae_sampled_decode(_dev(lc, torch.int32, "loss_cols"), _dev(lv, f32, "loss_targets"),
                                      _dev(ln, torch.int32, "loss_count"), _dev(z, f32, "z"), _dev(Wo, f32, "Wo"),

@@ -132,7 +132,7 @@ class CDAETrainer(BaseTrainer):
             covered += users.numel()
             item_lists = data['item_lists']
             if with_loss:
-                n = users.numel() * engine.cdae_sampled_decode_splits()
+                n = users.numel() * engine.cdae_sampled_decode_splits(users.numel())
                 if partials is None or partials.numel() < n:
                     partials = torch.empty(n, dtype=torch.float32, device=dev)
                 count.zero_()
