@@ -187,7 +187,8 @@ def other_workload(args):
     print(json.dumps(out), flush=True)
 
 
-EVENT_EVERY = 5                # launches are bracketed by HIP events on every 5th timed step: an event pair
+EVENT_EVERY = 5                # launches are bracketed by HIP events on every 5th timed step (odd / even steps
+                               # alternate between one pair around the group and one pair per launch): an event pair
                                # per launch on every step would itself cost ~20 % of a 100 us step
 
 
@@ -319,10 +320,13 @@ def main():
 
     # ---- roofline (HIP events inside the timed region, one pair per launch) ----------------------
     kt = step.kernel_times()                     # {name: (avg_us, launches, algorithmic bytes per launch)}
+    # single-GPU pull form: recorded steps alternate between one event pair around the whole launch group
+    # ("bpr_pull_step": the step's GPU time with its two launch gaps) and one pair per launch (the split)
+    group = kt.pop("bpr_pull_step", None) if len(kt) > 1 else None
     dom = max(kt, key=lambda k: kt[k][0] * kt[k][1])
     avg_us, launches, alg_bytes = kt[dom]
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
-    group_us = sum(v[0] for v in kt.values())
+    group_us = group[0] if group else sum(v[0] for v in kt.values())
     local_B = sum(t[0].numel() for t in pool) / len(pool)
     # HBM-side traffic per step from rocprofv3 PMC passes of this same command (FETCH_SIZE doubled
     # as MI355X_MICROARCH.md prescribes, + WRITE_SIZE), committed under profiles/ by
@@ -392,7 +396,7 @@ def main():
                 continue
             src = torch.cat([t[0] for t in pool])[:b], torch.cat([t[1] for t in pool])[:b], torch.cat([t[2] for t in pool])[:b]
             sec, k2 = time_steps_gpu(step, tuple(t.contiguous() for t in src), 50, 10)
-            ksum = sum(v[0] for v in k2.values()) * 1e-6
+            ksum = (k2["bpr_pull_step"][0] if "bpr_pull_step" in k2 and len(k2) > 1 else sum(v[0] for v in k2.values())) * 1e-6
             sweep[str(b)] = {"us_per_step": round(sec * 1e6, 1), "triplets_per_s": round(b / sec, 1),
                              "impl": step.impl.split(":")[0], "sum_kernel_us": round(ksum * 1e6, 1),
                              "frac": round(b * per_triplet / sec / 1e9 / HBM_PEAK_GBS, 4),

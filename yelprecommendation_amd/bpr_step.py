@@ -271,7 +271,9 @@ class BPRMFStep:
                 self._indexed = None
 
         def local_first():
-            if record and self.time_kernels and not multi:
+            if record and self.time_kernels and not multi and self.t % 2 == 0:
+                # (recorded steps alternate: odd ones bracket the whole launch group with ONE pair of events — its
+                # duration carries two launch gaps instead of three event pairs — even ones, here, each launch)
                 # the same three launches, each between its own pair of events; algorithmic bytes per
                 # SURVEY 8d split by what each launch must move at least once (ids, partner rows,
                 # gradient rows folded into the Adam pass; the dense Adam bytes listed apart)
