@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 24
+#define YR_ENGINE_VERSION 25
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -567,6 +567,16 @@ int yr_cdae_sparse_encode_t(const int32_t *cols, const float *vals, const int32_
                             int H, int64_t num_users, int act, float *z, int32_t *err_flag, void *stream);
 int yr_cdae_sparse_dwh_t(const int32_t *cols, const float *vals, const int32_t *count, const float *dz,
                          int64_t B, int64_t I, int H, float *dWhT, uint8_t *touched_items, void *stream);
+/* yr_cdae_hidden_bwd_dwh_t = yr_cdae_hidden_bwd + yr_cdae_sparse_dwh_t in one launch (a workgroup per batch row keeps
+ * the row's dz in registers): db_h += dz (float atomics: db_h zero on entry), dV[user] += dz (user marked), dWhT rows
+ * of the input items += dz * val (items marked), loss of the step from the decoder's partials (workgroup 0).
+ * pos_count: the spread count of loss positions (always needed for the loss; divides dz when scale_dz != 0).  H <= 512. */
+int yr_cdae_hidden_bwd_dwh_t(const int32_t *cols, const float *vals, const int32_t *count, const float *dz,
+                             const float *z, int act, int scale_dz, const int32_t *pos_count,
+                             const int64_t *user, int64_t B, int64_t I, int H, int64_t num_users, float *dV,
+                             uint8_t *touched_users, float *dbh, float *dWhT, uint8_t *touched_items,
+                             const float *partial_loss, int64_t n_partials, float *stats,
+                             double *loss_accum, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Device-side BPR triplet stream   (reference train.py:76-77: DataLoader(MFDataset, shuffle=True);

@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
-ENGINE_VERSION = 24
+ENGINE_VERSION = 25
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -90,6 +90,8 @@ SIGNATURES = {
     "yr_cdae_sparse_dwh": [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, C.c_int32, _p, _p, _p],
     "yr_cdae_sparse_encode_t": [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _int, _i64, _int, _p, _p, _p],
     "yr_cdae_sparse_dwh_t": [_p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p],
+    "yr_cdae_hidden_bwd_dwh_t": [_p, _p, _p, _p, _p, _int, _int, _p, _p, _i64, _i64, _int, _i64, _p, _p, _p, _p, _p, _p,
+                                 _i64, _p, _p, _p],
     "yr_triplet_sample": [_p, _p, _i64, _p, _p, _i64, _i64, C.c_uint64, C.c_uint64, _int, _i64, _i64,
                           _p, _p, _p, _p, _p],
 }

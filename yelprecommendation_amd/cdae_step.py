@@ -19,7 +19,7 @@ without materialising ``pred`` or the loss gradient w.r.t. it:
 
 Eleven launches (8 is a memset and two kernels) against ~26 through autograd, and 5 passes over [B, I]
 data instead of 11.  With ``transposed_wh`` (what CDAETrainer uses) steps 2 and 8 work on an [I, H] working copy of
-W_h: 8 becomes one launch (yr_cdae_sparse_dwh_t), 2 reads one 512-byte row per input item.
+W_h: 2 reads one 512-byte row per input item, 7 and 8 become ONE launch (yr_cdae_hidden_bwd_dwh_t).
 
 With NS-BCE the loss reads the prediction on the positions where target + negative_mask != 0 only (loss.py:14-16)
 — (1 + neg_times) x the positives of a row, a fraction of a percent of the catalogue — and its gradient w.r.t.
@@ -74,7 +74,8 @@ class CDAEStep:
         f32 = torch.float32
         self.dV = torch.zeros_like(V)                                          # all-zero between steps, like
         self.dWh = None if self.transposed_wh else torch.zeros_like(Wh)        # dW_h (or its transposed form)
-        self.dbh = torch.empty_like(bh)
+        self.dbh = torch.zeros_like(bh)                 # accumulated into by the fused hidden backward: cleared by Adam
+        self.hidden_size = H
         if decoder == "sampled":                                                # accumulated into: zero between steps
             self.dWo, self.dbo = torch.zeros_like(Wo), torch.zeros_like(bo)
         else:                                                                   # overwritten whole
@@ -206,19 +207,26 @@ class CDAEStep:
             engine.gemm_f32(self.G, self.z, transA=True, out=self.dWo, alpha_count=self.count, rowsum=self.dbo)
             engine.gemm_f32(self.G, Wo, out=self.dz, accumulate=True, split_k=max(1, min(256, Wo.shape[0] // 256)),
                             alpha_count=self.count)
-        engine.cdae_hidden_bwd(self.dz, self.z, model._hidden_act, user_id, self.dV, self.touched_users, self.dbh,
-                               self.partials, self.n_partials, self.count, self.stats, self.loss_accum,
-                               scale_dz=sampled)
-        if wt is not None:
-            engine.cdae_sparse_dwh_t(rows, self.dz, wt[3], wt[4])
+        if wt is not None and self.hidden_size <= 512:
+            # hidden layer's backward, db_h, dV, dW_h^T and the step's loss in one launch (db_h accumulates: the
+            # Adam launch clears it)
+            engine.cdae_hidden_bwd_dwh_t(rows, self.dz, self.z, model._hidden_act, user_id, self.count, self.dV,
+                                         self.touched_users, self.dbh, wt[3], wt[4], self.partials, self.n_partials,
+                                         self.stats, self.loss_accum, scale_dz=sampled)
         else:
-            engine.cdae_sparse_dwh(rows, self.dz, self.dWh)
+            engine.cdae_hidden_bwd(self.dz, self.z, model._hidden_act, user_id, self.dV, self.touched_users, self.dbh,
+                                   self.partials, self.n_partials, self.count, self.stats, self.loss_accum,
+                                   scale_dz=sampled)
+            if wt is not None:
+                engine.cdae_sparse_dwh_t(rows, self.dz, wt[3], wt[4])
+            else:
+                engine.cdae_sparse_dwh(rows, self.dz, self.dWh)
         group = self.optimizer.param_groups[0]
         st = [self.optimizer.state[q] for q in self.params]
         t = int(st[0]["step"]) + 1
         grads = (self.dWh, self.dbh, self.dV, self.dWo, self.dbo)
         marks = (None, None, self.touched_users, None, None)
-        clear = (1, 0, int(self.touched_users is None), 2 if sampled else 0, int(sampled))
+        clear = (1, 1, int(self.touched_users is None), 2 if sampled else 0, int(sampled))
         scaled = (False, False, False, sampled, sampled)
         tensors = [(q.data, g, s["exp_avg"], s["exp_avg_sq"], m, c, sc)
                    for q, g, s, m, c, sc in list(zip(self.params, grads, st, marks, clear, scaled))[1 if wt is not None else 0:]]

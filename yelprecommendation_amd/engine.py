@@ -586,6 +586,22 @@ def cdae_sparse_dwh_t(rows: "SparseRows", dz, dWhT, touched_items):
                                    _stream()), "yr_cdae_sparse_dwh_t")
 
 
+def cdae_hidden_bwd_dwh_t(rows: "SparseRows", dz, z, act, user, count, dV, touched_users, dbh, dWhT, touched_items,
+                          partial_loss, n_partials, stats, loss_accum=None, scale_dz=False):
+    """cdae_hidden_bwd + cdae_sparse_dwh_t in one launch (yr_cdae_hidden_bwd_dwh_t); ``dbh`` must be zero on entry."""
+    lib = _lib.load()
+    f32 = torch.float32
+    check(lib.yr_cdae_hidden_bwd_dwh_t(rows.cols.data_ptr(), rows.vals.data_ptr(), rows.count.data_ptr(),
+                                       _dev(dz, f32, "dz"), _dev(z, f32, "z"), int(act), 1 if scale_dz else 0,
+                                       _dev(count, torch.int32, "count"), _dev(user, torch.int64, "user"), rows.B,
+                                       rows.I, dz.shape[1], dV.shape[0], _dev(dV, f32, "dV"),
+                                       _opt(touched_users, torch.uint8, "touched_users"), _dev(dbh, f32, "dbh"),
+                                       _dev(dWhT, f32, "dWhT"), _dev(touched_items, torch.uint8, "touched_items"),
+                                       _opt(partial_loss, f32, "partial_loss"), int(n_partials),
+                                       _opt(stats, f32, "stats"), _opt(loss_accum, torch.float64, "loss_accum"),
+                                       _stream()), "yr_cdae_hidden_bwd_dwh_t")
+
+
 _dwh_scratch = {}
 
 
