@@ -147,6 +147,7 @@ __global__ __launch_bounds__(kListThreads) void cdae_train_lists_kernel(
         const bool drawn = (s_drawn[c >> 5] & bit) != 0;
         is_neg = !is_pos && (invert ? !drawn : drawn);
       }
+      if (__ballot(is_pos || is_neg || is_in) == 0ull) continue;   // nothing in these 64 columns (the usual case)
       float v = 0.0f;
       if (is_in) {
         v = 1.0f;
