@@ -55,6 +55,25 @@ def test_argument_checks_without_gpu():
     assert lib.yr_adam_dense(None, None, None, None, 16, 1e-3, 1e-3, 1.0, 0.9, 0.999, 1e-8, 0.0, 0, 0, None) == -2
     assert lib.yr_adam_dense(None, None, None, None, 0, 1e-3, 1e-3, 1.0, 0.9, 0.999, 1e-8, 0.0, 0, 0, None) == 0
     assert lib.yr_topk_masked(None, 1, 10, 10, None, None, None, 0.0, 100, None, None) == -2   # k > 64
+    # entry points added in round 2: sizes / helpers answer on the host, bad arguments come back as -2 / -1
+    assert lib.yr_bpr_mf_pull_item_buckets(38048, 64) == 2378 and lib.yr_bpr_mf_pull_item_buckets(38048, 48) == -2
+    assert lib.yr_cdae_sparse_part_columns(38048) == 1192 and lib.yr_cdae_decode_loss_partials(256, 38048) == 4 * 595
+    assert [lib.yr_cdae_sampled_decode_splits(b) for b in (0, 32, 256, 1024)] == [1, 8, 2, 1]
+    assert lib.yr_gemm_f32_ex(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, 1, None, None, None) == -2
+    assert lib.yr_gemm_f32_ex(0, 0, 0, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, 1, None, None, None) == 0    # empty
+    assert lib.yr_cdae_decode_loss(None, None, None, None, None, 8, 8, 6, 1, None, 8, None, None, None, None) == -2
+    assert lib.yr_cdae_sampled_decode(None, None, None, None, None, None, 8, 8, 300, 1, None, None, None, None, None,
+                                      None) == -1                                                   # H > 256
+    assert lib.yr_cdae_train_lists(None, None, None, None, None, 4, 4, 1 << 20, 5, 1, 2, 0.5, None, None, None, None,
+                                   None, None, None, None) == -2
+    assert lib.yr_cdae_train_lists(None, None, None, None, None, 0, 4, 10, 5, 1, 2, 0.5, None, None, None, None, None,
+                                   None, None, None) == 0                                           # empty batch
+    assert lib.yr_adam_dense_flat(None, None, None, None, None, None, None, None, None, None, 17, 1e-3, 1e-3, 1.0, 0.9,
+                                  0.999, 1e-8, 0.0, 0, None) == -2                                  # > 16 tensors
+    assert lib.yr_adam_dense_flat(None, None, None, None, None, None, None, None, None, None, 0, 1e-3, 1e-3, 1.0, 0.9,
+                                  0.999, 1e-8, 0.0, 0, None) == 0
+    assert lib.yr_mf_eval_topk_bias(None, None, None, None, 4, 64, 10, 10, None, None, 0.0, 17, None, None, 0, None,
+                                    None) == -2                                                     # k > 16
 
 
 def test_ops_refuse_cpu_tensors():
