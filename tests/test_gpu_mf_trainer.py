@@ -197,3 +197,24 @@ def test_checkpoint_resume_continues_the_run(g, tmp_path, device):
     c = MFTrainer(cfg, ni, nu)
     c.model.load_state_dict(a.model.state_dict())
     assert c.optimizer.state_dict()["state"] == {}
+
+
+def test_whole_epoch_validate_equals_per_batch_loop(device, tmp_path):
+    """MFTrainer.validate over the device-side EpochLoader: the sum over batches of the batch-mean loss in two
+    launches (full batches weighted 1 / batch_size, the short last batch 1 / its length) == the per-batch loop of
+    the reference's shape (trainers/mf_trainer.py:118-132) on the same sampled epoch; batch sizes that divide the
+    epoch, leave a remainder, and exceed it."""
+    from yelprecommendation_amd.data.synthetic import make_interactions_torch
+    from yelprecommendation_amd.data.triplets import EpochLoader, TripletSampler
+    from yelprecommendation_amd.trainers import MFTrainer
+    from yelprecommendation_amd.utils import make_config
+    nu, ni = 300, 500
+    u, i = make_interactions_torch(nu, ni, 12.0, seed=3, device=device)
+    for bs in (32, 100, u.numel(), 3 * u.numel()):
+        got = {}
+        for whole in (True, False):
+            torch.manual_seed(9)
+            t = MFTrainer(make_config("MF", device="cuda", model_dir=str(tmp_path), embed_size=32, batch_size=bs,
+                                      whole_epoch_validate=whole), ni, nu)
+            got[whole] = t.validate(EpochLoader(TripletSampler(u, i, nu, ni, seed=5), bs))
+        np.testing.assert_allclose(got[True], got[False], rtol=2e-6)

@@ -229,6 +229,21 @@ class MFTrainer(BaseTrainer):
         # reference mf_trainer.py:118-132
         self.model.eval()
         self._loss_accum.zero_()
+        from ..data.triplets import EpochLoader
+        if isinstance(valid_dataloader, EpochLoader) and self.cfg.get("whole_epoch_validate", True):
+            # the device-side loader holds the whole epoch: the sum over batches of the batch-MEAN loss is two
+            # launches — all full batches with weight 1 / batch_size, the short last one with 1 / its length —
+            # instead of one launch + one finalize per batch (9,600 batches at the reference's batch size 32:
+            # 194 ms of host time for 3 ms of kernels)
+            u, p, n = valid_dataloader.sampler.epoch(valid_dataloader.shuffle)
+            bs, total = valid_dataloader.batch_size, u.numel()
+            full = total // bs * bs
+            for lo, hi in ((0, full), (full, total)):
+                if hi > lo:
+                    self.model.bpr_loss_backward(u[lo:hi], p[lo:hi], n[lo:hi], loss_accum=self._loss_accum,
+                                                 backward=False, inv_batch=1.0 / min(bs, hi - lo))
+            self.model.check_indices()
+            return float(self._loss_accum.item())
         for data in valid_dataloader:
             user_id, pos_item, neg_item = self._batch(data)
             self.model.bpr_loss_backward(user_id, pos_item, neg_item, loss_accum=self._loss_accum, backward=False)
