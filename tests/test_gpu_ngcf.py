@@ -175,6 +175,12 @@ def test_trainer_run_matches_reference(g, tmp_path, device):
         vl = t.validate(ReplayLoader(g["valid_u"][vr0:vr1], g["valid_p"][vr0:vr1], g["valid_n"][vr0:vr1], vb[vb0:vb1]))
         np.testing.assert_allclose(tl, g["train_epoch_loss"][e], rtol=1e-4)
         np.testing.assert_allclose(vl, g["valid_epoch_loss"][e], rtol=1e-4)
+        # validate() propagates once and scores every batch on the same layers; re-propagating per batch (the
+        # reference's loop) must give the very same number
+        t.cfg.propagate_once = False
+        again = t.validate(ReplayLoader(g["valid_u"][vr0:vr1], g["valid_p"][vr0:vr1], g["valid_n"][vr0:vr1], vb[vb0:vb1]))
+        t.cfg.propagate_once = True
+        assert again == vl
         # feed evaluate() the positions the reference drew from its NumPy stream
         np.random.randint = lambda *a, **k: g["eval_positions"][e].copy()
         try:

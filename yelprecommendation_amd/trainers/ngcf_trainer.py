@@ -90,9 +90,19 @@ class NGCFTrainer(BaseTrainer):
         self.model.eval()
         self._loss_accum.zero_()
         with torch.no_grad():
+            # the parameters do not change during validation, so the K propagation layers are the same for every
+            # batch: computed once (the reference re-propagates the whole graph per batch, ngcf_trainer.py:124), then
+            # every batch is one scoring launch on them — the same kernels on the same data, bit-identical values
+            once = self.cfg.get("propagate_once", True)
+            layers = self.model.propagate(self.laplacian_matrix) if once else None
             for data in valid_dataloader:
                 user_id, pos_item, neg_item = self._batch(data)
-                pos_pred, neg_pred = self.model.bpr_forward(user_id, pos_item, neg_item, self.laplacian_matrix)
+                if once:
+                    pos_pred, neg_pred = engine.ngcf_score(layers, self.num_users, user_id.contiguous(),
+                                                           pos_item.contiguous(), neg_item.contiguous(),
+                                                           err_flag=self.model._flag())
+                else:
+                    pos_pred, neg_pred = self.model.bpr_forward(user_id, pos_item, neg_item, self.laplacian_matrix)
                 self._accumulate(self.loss(pos_pred, neg_pred))
         self.model.check_indices()
         return float(self._loss_accum.item())
