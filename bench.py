@@ -322,7 +322,7 @@ def main():
     kt = step.kernel_times()                     # {name: (avg_us, launches, algorithmic bytes per launch)}
     # single-GPU pull form: recorded steps alternate between one event pair around the whole launch group
     # ("bpr_pull_step": the step's GPU time with its two launch gaps) and one pair per launch (the split)
-    group = kt.pop("bpr_pull_step", None) if len(kt) > 1 else None
+    group = kt.pop("bpr_pull_step", None) if "owner_pass_item" in kt else None
     dom = max(kt, key=lambda k: kt[k][0] * kt[k][1])
     avg_us, launches, alg_bytes = kt[dom]
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
@@ -396,7 +396,7 @@ def main():
                 continue
             src = torch.cat([t[0] for t in pool])[:b], torch.cat([t[1] for t in pool])[:b], torch.cat([t[2] for t in pool])[:b]
             sec, k2 = time_steps_gpu(step, tuple(t.contiguous() for t in src), 50, 10)
-            ksum = (k2["bpr_pull_step"][0] if "bpr_pull_step" in k2 and len(k2) > 1 else sum(v[0] for v in k2.values())) * 1e-6
+            ksum = (k2["bpr_pull_step"][0] if "owner_pass_item" in k2 else sum(v[0] for v in k2.values())) * 1e-6
             sweep[str(b)] = {"us_per_step": round(sec * 1e6, 1), "triplets_per_s": round(b / sec, 1),
                              "impl": step.impl.split(":")[0], "sum_kernel_us": round(ksum * 1e6, 1),
                              "frac": round(b * per_triplet / sec / 1e9 / HBM_PEAK_GBS, 4),
