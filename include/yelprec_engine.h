@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 25
+#define YR_ENGINE_VERSION 26
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -407,16 +407,27 @@ int yr_mf_scores_gemm(const float *U, const float *I, const int64_t *users, int6
  *   scores of the items in mask_idx[mask_ptr[r] .. mask_ptr[r+1]) to mask_value; score
  *   descending, item id ascending among equal scores.  k <= 16.
  * The mask lists must be sorted ASCENDING inside each row (the kernel walks them with a cursor as
- * it sweeps the catalogue).  mask_ptr may be NULL.  f32 MFMA scores as yr_mf_scores_gemm.
- * workspace: yr_mf_eval_topk_workspace_bytes(nrows, num_items, k) bytes of device memory (may be 0);
- *   it holds the per-slice partial lists when the catalogue is cut into slices to fill the chip.
- *   With workspace NULL or too small the kernel runs unsliced (same result, slower).
+ * it sweeps the catalogue).  mask_ptr may be NULL.
+ * mode: how the matrix cores compute the f32 scores —
+ *   YR_EVAL_F32     v_mfma_f32_32x32x2_f32 on the f32 tables (as yr_mf_scores_gemm);
+ *   YR_EVAL_BF16X3  every operand as the sum of three bfloat16 terms (x = x1 + x2 + x3 to 2^-27 |x|), every product
+ *                   as its six partial products of weight >= 2^-18, accumulated in f32 by v_mfma_f32_32x32x16_bf16:
+ *                   what is dropped is below 2^-25 |x y|, less than the f32 rounding of the product, so the scores
+ *                   differ from YR_EVAL_F32 by what two f32 summation orders differ by, at 3/8 of the matrix-core
+ *                   cycles.  The item planes (6 D bytes per item) are rebuilt from I by every call.
+ * workspace: yr_mf_eval_topk_workspace_bytes(nrows, num_items, D, k, mode) bytes of device memory (may be 0 in
+ *   YR_EVAL_F32): first the item planes of YR_EVAL_BF16X3 (yr_mf_eval_topk_planes_bytes(num_items, D): required in
+ *   that mode, YR_ERR_BADARG without), then the per-slice partial lists when the catalogue is cut into slices to
+ *   fill the chip; without room for those the kernel runs unsliced (same result, slower).
  * ------------------------------------------------------------------------- */
-int64_t yr_mf_eval_topk_workspace_bytes(int64_t nrows, int64_t num_items, int k);
+#define YR_EVAL_F32 0
+#define YR_EVAL_BF16X3 1
+int64_t yr_mf_eval_topk_planes_bytes(int64_t num_items, int D);
+int64_t yr_mf_eval_topk_workspace_bytes(int64_t nrows, int64_t num_items, int D, int k, int mode);
 int yr_mf_eval_topk(const float *U, const float *I, const int64_t *users, int64_t nrows, int D,
                     int64_t num_users, int64_t num_items,
                     const int64_t *mask_ptr, const int64_t *mask_idx, float mask_value,
-                    int k, int64_t *out, void *workspace, int64_t workspace_bytes,
+                    int k, int64_t *out, void *workspace, int64_t workspace_bytes, int mode,
                     int32_t *err_flag, void *stream);
 /* yr_mf_eval_topk_bias: the same with scores U[users[r]] . I[j] + item_bias[j] (item_bias NULL: yr_mf_eval_topk).
  *   The evaluation of CDAE (trainers/cdae_trainer.py:90-144) for ALL users at once: U = the hidden rows z
@@ -426,7 +437,7 @@ int yr_mf_eval_topk(const float *U, const float *I, const int64_t *users, int64_
 int yr_mf_eval_topk_bias(const float *U, const float *I, const float *item_bias, const int64_t *users,
                          int64_t nrows, int D, int64_t num_users, int64_t num_items,
                          const int64_t *mask_ptr, const int64_t *mask_idx, float mask_value,
-                         int k, int64_t *out, void *workspace, int64_t workspace_bytes,
+                         int k, int64_t *out, void *workspace, int64_t workspace_bytes, int mode,
                          int32_t *err_flag, void *stream);
 
 /* ---------------------------------------------------------------------------

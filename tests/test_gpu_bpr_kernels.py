@@ -207,13 +207,15 @@ def test_fused_eval_topk_edge_cases(device, d):
     idx = np.concatenate(lists).astype(np.int64)
     t = lambda a: torch.from_numpy(a).to(device)
     for k in (1, 10, 16):
-        a = engine.mf_recommend(t(U), t(I), t(users), t(ptr), t(idx), k, fused=True).cpu().numpy()
         b = engine.mf_recommend(t(U), t(I), t(users), t(ptr), t(idx), k, fused=False).cpu().numpy()
-        assert_topk_equal_up_to_near_ties(a, b, U, I, users, lists)
+        for precision in ("bf16x3", "f32"):
+            a = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, precision=precision).cpu().numpy()
+            assert_topk_equal_up_to_near_ties(a, b, U, I, users, lists)
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
 @pytest.mark.parametrize("ni,expect_slices", [(4100, 2), (16411, 8)])
-def test_fused_eval_catalogue_slices_equal_one_slice(device, ni, expect_slices):
+def test_fused_eval_catalogue_slices_equal_one_slice(device, ni, expect_slices, precision):
     """The fused kernel cuts the catalogue into slices (one workgroup per 128 users x slice, partial
     top-k lists merged by a second kernel) when there are few user rows: the result must be
     IDENTICAL to the one-slice form (same scores, same tie order), masks included — also when a
@@ -238,9 +240,12 @@ def test_fused_eval_catalogue_slices_equal_one_slice(device, ni, expect_slices):
     t = lambda a: torch.from_numpy(a).to(device)
     lib = _lib.load()
     for k in (1, 10, 16):
-        assert lib.yr_mf_eval_topk_workspace_bytes(n, ni, k) == n * expect_slices * k * 8
-        a = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, sliced=True).cpu().numpy()
-        b = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, sliced=False).cpu().numpy()
+        planes = lib.yr_mf_eval_topk_planes_bytes(ni, d)
+        assert planes == -(-ni * 6 * d // 256) * 256
+        assert lib.yr_mf_eval_topk_workspace_bytes(n, ni, d, k, 0) == n * expect_slices * k * 8
+        assert lib.yr_mf_eval_topk_workspace_bytes(n, ni, d, k, 1) == planes + n * expect_slices * k * 8
+        a = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, sliced=True, precision=precision).cpu().numpy()
+        b = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, sliced=False, precision=precision).cpu().numpy()
         np.testing.assert_array_equal(a, b)
         c = engine.mf_recommend(t(U), t(I), t(users), t(ptr), t(idx), k, fused=False).cpu().numpy()
         assert_topk_equal_up_to_near_ties(a, c, U, I, users, lists)
@@ -248,8 +253,9 @@ def test_fused_eval_catalogue_slices_equal_one_slice(device, ni, expect_slices):
             assert not set(a[r].tolist()) & set(lists[r].tolist())
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
 @pytest.mark.parametrize("d", [16, 32, 64, 128])
-def test_fused_eval_with_item_bias(device, d):
+def test_fused_eval_with_item_bias(device, d, precision):
     """yr_mf_eval_topk_bias: scores U[u] . I[j] + bias[j] (the CDAE decoder before its sigmoid).  The bias is the
     MFMA accumulator's initial value, so the kernel must equal the bias-free kernel on tables augmented by one
     column ([u, 1] . [i, b]) — checked through the near-tie comparison against float64 scores — sliced and
@@ -270,11 +276,12 @@ def test_fused_eval_with_item_bias(device, d):
         exact[r, lists[r]] = -np.inf
     for k in (4, 10, 16):
         want = np.argsort(-exact, axis=1, kind="stable")[:, :k]
-        a = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, item_bias=t(bias)).cpu().numpy()
-        b = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, item_bias=t(bias), sliced=False).cpu().numpy()
+        a = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, item_bias=t(bias), precision=precision).cpu().numpy()
+        b = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, item_bias=t(bias), sliced=False,
+                                precision=precision).cpu().numpy()
         np.testing.assert_array_equal(a, b)
         assert_topk_equal_up_to_near_ties(a, want, Ua, Ia, users, lists)
-        plain = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k).cpu().numpy()
+        plain = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, precision=precision).cpu().numpy()
         assert (plain != a).any()                                            # the bias matters
 
 

@@ -72,8 +72,14 @@ def test_argument_checks_without_gpu():
                                   0.999, 1e-8, 0.0, 0, None) == -2                                  # > 16 tensors
     assert lib.yr_adam_dense_flat(None, None, None, None, None, None, None, None, None, None, 0, 1e-3, 1e-3, 1.0, 0.9,
                                   0.999, 1e-8, 0.0, 0, None) == 0
-    assert lib.yr_mf_eval_topk_bias(None, None, None, None, 4, 64, 10, 10, None, None, 0.0, 17, None, None, 0, None,
+    assert lib.yr_mf_eval_topk_bias(None, None, None, None, 4, 64, 10, 10, None, None, 0.0, 17, None, None, 0, 0, None,
                                     None) == -2                                                     # k > 16
+    assert lib.yr_mf_eval_topk_bias(None, None, None, None, 4, 64, 10, 10, None, None, 0.0, 10, None, None, 0, 2, None,
+                                    None) == -2                                                     # unknown mode
+    assert lib.yr_mf_eval_topk_planes_bytes(1000, 64) == 1000 * 6 * 64
+    assert lib.yr_mf_eval_topk_planes_bytes(1000, 48) == -2
+    assert lib.yr_mf_eval_topk_workspace_bytes(128, 1000, 64, 10, 1) == 1000 * 6 * 64               # one slice: planes only
+    assert lib.yr_mf_eval_topk_workspace_bytes(128, 1000, 64, 10, 0) == 0
 
 
 def test_ops_refuse_cpu_tensors():

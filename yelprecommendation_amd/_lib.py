@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
-ENGINE_VERSION = 25
+ENGINE_VERSION = 26
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -70,9 +70,10 @@ SIGNATURES = {
     "yr_bpr_mf_pull_item_buckets": [_i64, _int],
     "yr_loss_finalize": [_p, _f, _p, _p, _p],
     "yr_mf_scores_gemm": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _p, _p],
-    "yr_mf_eval_topk_workspace_bytes": [_i64, _i64, _int],
-    "yr_mf_eval_topk": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _f, _int, _p, _p, _i64, _p, _p],
-    "yr_mf_eval_topk_bias": [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _f, _int, _p, _p, _i64, _p, _p],
+    "yr_mf_eval_topk_planes_bytes": [_i64, _int],
+    "yr_mf_eval_topk_workspace_bytes": [_i64, _i64, _int, _int, _int],
+    "yr_mf_eval_topk": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _f, _int, _p, _p, _i64, _int, _p, _p],
+    "yr_mf_eval_topk_bias": [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _f, _int, _p, _p, _i64, _int, _p, _p],
     "yr_topk_masked": [_p, _i64, _i64, _i64, _p, _p, _p, _f, _int, _p, _p],
     "yr_rank_metrics_workspace_bytes": [_i64],
     "yr_rank_metrics": [_p, _i64, _int, _p, _p, _p, _p, _p, _p],
@@ -132,7 +133,8 @@ def load():
                       "yr_rank_metrics_workspace_bytes": C.c_int64,
                       "yr_cdae_sparse_part_columns": C.c_int64,
                       "yr_cdae_decode_loss_partials": C.c_int64,
-                      "yr_mf_eval_topk_workspace_bytes": C.c_int64}.get(name, C.c_int)
+                      "yr_mf_eval_topk_workspace_bytes": C.c_int64,
+                      "yr_mf_eval_topk_planes_bytes": C.c_int64}.get(name, C.c_int)
     v = lib.yr_engine_version()
     if v != ENGINE_VERSION:
         raise EngineError(f"engine ABI version {v} != expected {ENGINE_VERSION}; rebuild the library")

@@ -31,6 +31,7 @@
 namespace yr {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 constexpr int kEtUsersPerWave = 32;
 constexpr int kEtWaves = 4;
@@ -50,6 +51,9 @@ constexpr int kEtMaxK = 16;
 #endif
 #ifndef YR_ET_TARGET_WGS
 #define YR_ET_TARGET_WGS 768
+#endif
+#ifndef YR_ET_SPLIT_CHUNK
+#define YR_ET_SPLIT_CHUNK 32
 #endif
 constexpr int kEtFlushAt = YR_ET_FLUSH_AT;             // flush when some lane holds more than this
 constexpr int kEtCheckEvery = YR_ET_CHECK_EVERY;       // ... checked after this many accumulator registers
@@ -87,23 +91,85 @@ __device__ __forceinline__ void et_bubble(float (&Ls)[KK], int32_t (&Li)[KK], fl
   }
 }
 
+// x = x1 + x2 + x3 with three bfloat16 terms (round to nearest each time; the residuals x - x1 and x - x1 - x2 are
+// exact in f32): |x - x1 - x2 - x3| <= 2^-27 |x|.  Returns the three 16-bit patterns.
+__device__ __forceinline__ void et_split3(float x, uint32_t& b1, uint32_t& b2, uint32_t& b3) {
+  const __bf16 h1 = (__bf16)x;
+  const float r1 = x - (float)h1;
+  const __bf16 h2 = (__bf16)r1;
+  const float r2 = r1 - (float)h2;
+  const __bf16 h3 = (__bf16)r2;
+  b1 = __builtin_bit_cast(unsigned short, h1);
+  b2 = __builtin_bit_cast(unsigned short, h2);
+  b3 = __builtin_bit_cast(unsigned short, h3);
+}
+
+// eight consecutive floats -> their three bf16 planes, eight 16-bit values (one uint4) each
+__device__ __forceinline__ void et_split3x8(const float4 lo, const float4 hi, uint4& p1, uint4& p2, uint4& p3) {
+  const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  uint32_t w1[4], w2[4], w3[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    uint32_t a1, a2, a3, c1, c2, c3;
+    et_split3(x[2 * m], a1, a2, a3);
+    et_split3(x[2 * m + 1], c1, c2, c3);
+    w1[m] = a1 | (c1 << 16);
+    w2[m] = a2 | (c2 << 16);
+    w3[m] = a3 | (c3 << 16);
+  }
+  p1 = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+  p2 = make_uint4(w2[0], w2[1], w2[2], w2[3]);
+  p3 = make_uint4(w3[0], w3[1], w3[2], w3[3]);
+}
+
+// planes[(row * 3 + p) * D + d] = term p of X[row * D + d]: the item table as the split kernel stages it
+// (6 D bytes per item, contiguous).  One thread per eight floats.
+__global__ __launch_bounds__(kBlock) void et_split_rows_kernel(const float* __restrict__ X, int64_t groups, int D8,
+                                                               uint4* __restrict__ planes) {
+  const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (g >= groups) return;
+  const float4 lo = *reinterpret_cast<const float4*>(X + g * 8);
+  const float4 hi = *reinterpret_cast<const float4*>(X + g * 8 + 4);
+  uint4 p1, p2, p3;
+  et_split3x8(lo, hi, p1, p2, p3);
+  const int64_t row = g / D8;
+  const int c = (int)(g % D8);
+  planes[(row * 3 + 0) * D8 + c] = p1;
+  planes[(row * 3 + 1) * D8 + c] = p2;
+  planes[(row * 3 + 2) * D8 + c] = p3;
+}
+
 // BIAS: score = <user, item> + item_bias[item] — the decoder of CDAE, z . W_o[i] + b_o[i] (models/cdae.py:52), whose
 // sigmoid is monotone, so the top-k of the pre-activations is the top-k of the predictions.  The bias enters as
 // the initial value of the MFMA accumulator (staged through LDS with the item chunk): no extra instruction per score.
-template <int D, int KK, bool BIAS>
+//
+// SPLIT: the same f32 scores from bf16 matrix instructions.  Every operand is the sum of three bf16 terms
+// (et_split3), every product the six partial products whose weight is 2^-18 or more — x1 y1, x1 y2, x2 y1, x2 y2,
+// x1 y3, x3 y1; what is dropped is below 2^-25 |x y|, under the f32 rounding of the product itself — accumulated in
+// f32 by v_mfma_f32_32x32x16_bf16: 6 x 4 instructions of 32 cycles per 32-item tile at D = 64 against 32 of 64 cycles
+// (v_mfma_f32_32x32x2_f32).  The accumulator layout is the same, so is everything after it.  The items arrive
+// pre-split (et_split_rows_kernel, `I` is then the plane table), the users are split once into registers.
+template <int D, int KK, bool BIAS, bool SPLIT>
 __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
-    const float* __restrict__ U, const float* __restrict__ I, const float* __restrict__ item_bias,
+    const float* __restrict__ U, const void* __restrict__ I_any, const float* __restrict__ item_bias,
     const int64_t* __restrict__ users, int64_t nrows,
     int64_t num_users, int num_items, const int64_t* __restrict__ mask_ptr, const int64_t* __restrict__ mask_idx,
     float mask_value, int k, int64_t* __restrict__ out, TopEntry* __restrict__ partial, int items_per_slice,
     int32_t* __restrict__ err_flag) {
   constexpr int HALF = D / 2;
-  constexpr int PITCH = D + 4;
-  constexpr int NV = kEtChunkItems * (D / 4) / kEtThreads;       // float4 per thread per chunk (>= 1)
-  static_assert(NV >= 1, "chunk too small for this D");
-  __shared__ __attribute__((aligned(16))) float s_items[2][kEtChunkItems * PITCH];   // double-buffered
+  constexpr int KB = D / 16;                                      // SPLIT: 16-deep matrix instructions per plane pair
+  // items per LDS stage: 64 where three workgroups per CU fit with it (f32; SPLIT at D <= 32), else 32 — except
+  // SPLIT at D = 64 with 16-entry lists, whose registers allow two workgroups per CU either way
+  constexpr int CH = !SPLIT ? kEtChunkItems : (D <= 32 ? 64 : (D == 64 && KK > 10 ? 64 : YR_ET_SPLIT_CHUNK));
+  // bytes per staged item: D + 4 floats, or three bf16 planes + 16 (an odd number of 16-byte units either way:
+  // the 32 rows of a ds_read_b128 fall into different banks)
+  constexpr int ROWB = SPLIT ? 6 * D + 16 : 4 * (D + 4);
+  constexpr int ROW16 = SPLIT ? 3 * D / 8 : D / 4;                // 16-byte units of payload per item
+  constexpr int NV = (CH * ROW16 + kEtThreads - 1) / kEtThreads;  // 16-byte units per thread per chunk
+  __shared__ __attribute__((aligned(16))) unsigned char s_items[2][CH * ROWB];   // double-buffered
   __shared__ TopEntry s_buf[kEtBufCap][kEtThreads];               // slot-major: conflict-free per slot
-  __shared__ __attribute__((aligned(16))) float s_bias[2][BIAS ? kEtChunkItems : 4];
+  __shared__ __attribute__((aligned(16))) float s_bias[2][BIAS ? CH : 4];
+  const uint4* __restrict__ I16 = static_cast<const uint4*>(I_any);   // f32 rows or plane rows, 16 bytes at a time
 
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int i = lane & 31, h = lane >> 5;
@@ -111,8 +177,10 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
   const int item_lo = blockIdx.y * items_per_slice;  // this workgroup's slice of the catalogue
   const int item_hi = min(num_items, item_lo + items_per_slice);
 
-  // B operand: this lane's half of its user's row (zeros for rows beyond the input / bad ids)
-  float ub[HALF];
+  // B operand: this lane's half of its user's row (zeros for rows beyond the input / bad ids) — f32: dims
+  // [h D/2, (h+1) D/2); SPLIT: dims 16 kb + 8 h + j of every 16-deep block kb, three planes
+  float ub[SPLIT ? 1 : HALF];
+  uint4 us[SPLIT ? 3 : 1][SPLIT ? KB : 1];
   bool ok = row < nrows;
   {
     int64_t uid = ok ? users[row] : 0;
@@ -120,11 +188,23 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
       if (err_flag) atomicOr(err_flag, YR_FLAG_BAD_USER);
       ok = false;
     }
+    if constexpr (SPLIT) {
 #pragma unroll
-    for (int q = 0; q < HALF / 4; ++q) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) v = *reinterpret_cast<const float4*>(U + uid * D + h * HALF + 4 * q);
-      ub[4 * q + 0] = v.x; ub[4 * q + 1] = v.y; ub[4 * q + 2] = v.z; ub[4 * q + 3] = v.w;
+      for (int kb = 0; kb < KB; ++kb) {
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+        if (ok) {
+          lo = *reinterpret_cast<const float4*>(U + uid * D + 16 * kb + 8 * h);
+          hi = *reinterpret_cast<const float4*>(U + uid * D + 16 * kb + 8 * h + 4);
+        }
+        et_split3x8(lo, hi, us[0][kb], us[1][kb], us[2][kb]);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < HALF / 4; ++q) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float4*>(U + uid * D + h * HALF + 4 * q);
+        ub[4 * q + 0] = v.x; ub[4 * q + 1] = v.y; ub[4 * q + 2] = v.z; ub[4 * q + 3] = v.w;
+      }
     }
   }
 
@@ -161,25 +241,27 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
 
   // register staging of the item chunks: the loads of chunk c+1 are issued before the tiles of
   // chunk c are computed and land in LDS after the next barrier (global latency hidden under MFMA)
-  float4 stage[NV];
+  uint4 stage[NV];
   float stage_b = 0.0f;
   auto fetch = [&](int c0) {
-    if (BIAS && threadIdx.x < kEtChunkItems)
+    if (BIAS && threadIdx.x < CH)
       stage_b = c0 + (int)threadIdx.x < item_hi ? item_bias[c0 + threadIdx.x] : 0.0f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int q = threadIdx.x + v * kEtThreads;
-      const int r = q / (D / 4), c = q % (D / 4);
-      stage[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c0 + r < item_hi) stage[v] = *reinterpret_cast<const float4*>(I + (int64_t)(c0 + r) * D + 4 * c);
+      const int r = q / ROW16, c = q % ROW16;
+      stage[v] = make_uint4(0u, 0u, 0u, 0u);
+      if ((CH * ROW16 % kEtThreads == 0 || q < CH * ROW16) && c0 + r < item_hi)
+        stage[v] = I16[(int64_t)(c0 + r) * ROW16 + c];
     }
   };
-  auto stash = [&](float* dst, int buf) {
-    if (BIAS && threadIdx.x < kEtChunkItems) s_bias[buf][threadIdx.x] = stage_b;
+  auto stash = [&](unsigned char* dst, int buf) {
+    if (BIAS && threadIdx.x < CH) s_bias[buf][threadIdx.x] = stage_b;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int q = threadIdx.x + v * kEtThreads;
-      *reinterpret_cast<float4*>(dst + (q / (D / 4)) * PITCH + 4 * (q % (D / 4))) = stage[v];
+      if (CH * ROW16 % kEtThreads == 0 || q < CH * ROW16)
+        *reinterpret_cast<uint4*>(dst + (q / ROW16) * ROWB + 16 * (q % ROW16)) = stage[v];
     }
   };
   [[maybe_unused]] long long ph_mfma = 0, ph_mask = 0, ph_epi = 0, ph_flush = 0, ph_sync = 0, ph_total = ET_CLK();
@@ -187,13 +269,13 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
   stash(s_items[0], 0);
   __syncthreads();
   int cur = 0;
-  for (int c0 = item_lo; c0 < item_hi; c0 += kEtChunkItems) {
-    const bool more = c0 + kEtChunkItems < item_hi;
-    if (more) fetch(c0 + kEtChunkItems);             // lands in the other buffer at the end of this chunk
-    const float* chunk = s_items[cur];
+  for (int c0 = item_lo; c0 < item_hi; c0 += CH) {
+    const bool more = c0 + CH < item_hi;
+    if (more) fetch(c0 + CH);                        // lands in the other buffer at the end of this chunk
+    const unsigned char* chunk = s_items[cur];
 
 #pragma unroll 1
-    for (int t = 0; t < kEtChunkItems / 32; ++t) {
+    for (int t = 0; t < CH / 32; ++t) {
       const int item0 = c0 + t * 32;
       if (item0 >= item_hi) break;                   // wave-uniform
       // ---- scores: acc[reg] = <item item0 + row(reg, h), user of this lane>
@@ -206,8 +288,26 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
           acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
         }
       }
-      {
-        const float* src = chunk + (t * 32 + i) * PITCH + h * HALF;
+      if constexpr (SPLIT) {
+        // item row i of the tile, dims 16 kb + 8 h + j: one ds_read_b128 per plane and block; the small terms first
+        const unsigned char* src = chunk + (t * 32 + i) * ROWB + 16 * h;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(src + 32 * kb);
+          const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(src + 2 * D + 32 * kb);
+          const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(src + 4 * D + 32 * kb);
+          const bf16x8 u1 = __builtin_bit_cast(bf16x8, us[0][kb]);
+          const bf16x8 u2 = __builtin_bit_cast(bf16x8, us[1][kb]);
+          const bf16x8 u3 = __builtin_bit_cast(bf16x8, us[2][kb]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, u1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, u3, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, u2, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, u1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, u2, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, u1, acc, 0, 0, 0);
+        }
+      } else {
+        const float* src = reinterpret_cast<const float*>(chunk) + (t * 32 + i) * (D + 4) + h * HALF;
 #pragma unroll
         for (int q = 0; q < HALF / 4; ++q) {
           const float4 b = *reinterpret_cast<const float4*>(src + 4 * q);
@@ -376,21 +476,47 @@ static int et_slices(int64_t nrows, int64_t num_items) {
   return (int)(S < 1 ? 1 : S);
 }
 
-extern "C" int64_t yr_mf_eval_topk_workspace_bytes(int64_t nrows, int64_t num_items, int k) {
-  if (nrows < 0 || num_items <= 0 || k <= 0 || k > kEtMaxK) return YR_ERR_BADARG;
+// SPLIT mode: the item planes come first in the workspace, the partial lists of the slices after them
+static int64_t et_plane_bytes(int64_t num_items, int D) { return (num_items * 6 * D + 255) / 256 * 256; }
+
+extern "C" int64_t yr_mf_eval_topk_planes_bytes(int64_t num_items, int D) {
+  if (num_items <= 0 || (D != 16 && D != 32 && D != 64 && D != 128)) return YR_ERR_BADARG;
+  return et_plane_bytes(num_items, D);
+}
+
+extern "C" int64_t yr_mf_eval_topk_workspace_bytes(int64_t nrows, int64_t num_items, int D, int k, int mode) {
+  if (nrows < 0 || num_items <= 0 || k <= 0 || k > kEtMaxK || (mode != YR_EVAL_F32 && mode != YR_EVAL_BF16X3) ||
+      (D != 16 && D != 32 && D != 64 && D != 128))
+    return YR_ERR_BADARG;
   const int S = et_slices(nrows, num_items);
-  return S > 1 ? nrows * S * k * (int64_t)sizeof(TopEntry) : 0;
+  return (mode == YR_EVAL_BF16X3 ? et_plane_bytes(num_items, D) : 0) +
+         (S > 1 ? nrows * S * k * (int64_t)sizeof(TopEntry) : 0);
 }
 
 extern "C" int yr_mf_eval_topk_bias(const float* U, const float* I, const float* item_bias, const int64_t* users,
                                     int64_t nrows, int D, int64_t num_users, int64_t num_items,
                                     const int64_t* mask_ptr, const int64_t* mask_idx, float mask_value, int k,
-                                    int64_t* out, void* workspace, int64_t workspace_bytes, int32_t* err_flag,
+                                    int64_t* out, void* workspace, int64_t workspace_bytes, int mode, int32_t* err_flag,
                                     void* stream) {
-  if (nrows < 0 || num_users <= 0 || num_items <= 0 || num_items > 0x7ffffff0 || k <= 0 || k > kEtMaxK)
+  if (nrows < 0 || num_users <= 0 || num_items <= 0 || num_items > 0x7ffffff0 || k <= 0 || k > kEtMaxK ||
+      (mode != YR_EVAL_F32 && mode != YR_EVAL_BF16X3) || workspace_bytes < 0)
     return YR_ERR_BADARG;
+  if (D != 16 && D != 32 && D != 64 && D != 128) return YR_ERR_UNSUPPORTED;
   if (nrows == 0) return 0;
   if (!U || !I || !users || !out || (mask_ptr && !mask_idx)) return YR_ERR_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const bool split = mode == YR_EVAL_BF16X3;
+  const void* items = I;
+  if (split) {
+    const int64_t pb = et_plane_bytes(num_items, D);
+    if (!workspace || workspace_bytes < pb) return YR_ERR_BADARG;             // the planes are not optional
+    const int64_t groups = num_items * (D / 8);
+    hipLaunchKernelGGL(et_split_rows_kernel, dim3((unsigned)((groups + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, I,
+                       groups, D / 8, static_cast<uint4*>(workspace));
+    items = workspace;
+    workspace = static_cast<char*>(workspace) + pb;
+    workspace_bytes -= pb;
+  }
   int S = et_slices(nrows, num_items);
   if (S > 1 && (!workspace || workspace_bytes < nrows * S * k * (int64_t)sizeof(TopEntry))) S = 1;   // no room: one slice
   int per = (int)((num_items + S - 1) / S);
@@ -398,14 +524,18 @@ extern "C" int yr_mf_eval_topk_bias(const float* U, const float* I, const float*
   S = (int)((num_items + per - 1) / per);
   TopEntry* partial = S > 1 ? static_cast<TopEntry*>(workspace) : nullptr;
   const dim3 grid((unsigned)((nrows + kEtUsers - 1) / kEtUsers), (unsigned)S);
-  hipStream_t s = (hipStream_t)stream;
-#define YR_ET_LAUNCH_B(DD, KK, BB)                                                                                \
-  hipLaunchKernelGGL((mf_eval_topk_kernel<DD, KK, BB>), grid, dim3(kEtThreads), 0, s, U, I, item_bias, users, nrows, \
-                     num_users, (int)num_items, mask_ptr, mask_idx, mask_value, k, out, partial, per, err_flag)
-#define YR_ET_LAUNCH(DD, KK)                    \
-  do {                                          \
-    if (item_bias) YR_ET_LAUNCH_B(DD, KK, true); \
-    else YR_ET_LAUNCH_B(DD, KK, false);         \
+#define YR_ET_LAUNCH_B(DD, KK, BB, SS)                                                                              \
+  hipLaunchKernelGGL((mf_eval_topk_kernel<DD, KK, BB, SS>), grid, dim3(kEtThreads), 0, s, U, items, item_bias, users, \
+                     nrows, num_users, (int)num_items, mask_ptr, mask_idx, mask_value, k, out, partial, per, err_flag)
+#define YR_ET_LAUNCH(DD, KK)                                 \
+  do {                                                       \
+    if (item_bias) {                                         \
+      if (split) YR_ET_LAUNCH_B(DD, KK, true, true);         \
+      else YR_ET_LAUNCH_B(DD, KK, true, false);              \
+    } else {                                                 \
+      if (split) YR_ET_LAUNCH_B(DD, KK, false, true);        \
+      else YR_ET_LAUNCH_B(DD, KK, false, false);             \
+    }                                                        \
   } while (0)
 #define YR_ET_CASE(DD)                                     \
   case DD:                                                 \
@@ -432,9 +562,9 @@ extern "C" int yr_mf_eval_topk_bias(const float* U, const float* I, const float*
 extern "C" int yr_mf_eval_topk(const float* U, const float* I, const int64_t* users, int64_t nrows, int D,
                                int64_t num_users, int64_t num_items, const int64_t* mask_ptr,
                                const int64_t* mask_idx, float mask_value, int k, int64_t* out, void* workspace,
-                               int64_t workspace_bytes, int32_t* err_flag, void* stream) {
+                               int64_t workspace_bytes, int mode, int32_t* err_flag, void* stream) {
   return yr_mf_eval_topk_bias(U, I, nullptr, users, nrows, D, num_users, num_items, mask_ptr, mask_idx, mask_value, k,
-                              out, workspace, workspace_bytes, err_flag, stream);
+                              out, workspace, workspace_bytes, mode, err_flag, stream);
 }
 
 #ifdef YR_ET_STAMPS

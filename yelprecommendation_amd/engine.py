@@ -759,19 +759,28 @@ def sort_mask_rows(mask_ptr, mask_idx):
     return mask_idx[order].contiguous()
 
 
+EVAL_MODES = {"f32": 0, "bf16x3": 1}          # YR_EVAL_F32 / YR_EVAL_BF16X3 (include/yelprec_engine.h)
+
+
 def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALUE, out=None, sliced=True,
-                 item_bias=None):
+                 item_bias=None, precision="bf16x3"):
     """Fused full-catalogue scoring + mask + top-k (no score matrix).  ``mask_idx_sorted``: CSR mask
     lists with ascending ids inside each row (see :func:`sort_mask_rows`).  ``sliced=False`` withholds
-    the workspace, i.e. forces the one-slice form of the kernel (tests).  ``item_bias``: scores
-    U[u] . I[j] + item_bias[j] (the CDAE decoder before its sigmoid)."""
+    the room for the partial lists, i.e. forces the one-slice form of the kernel (tests).  ``item_bias``: scores
+    U[u] . I[j] + item_bias[j] (the CDAE decoder before its sigmoid).  ``precision``: "bf16x3" — f32 scores from
+    three-term bfloat16 splits of both operands on the bf16 matrix instructions (six partial products, error below
+    the f32 rounding of a product) — or "f32", the f32 matrix instruction itself."""
     lib = _lib.load()
     nu, ni, d = _table_dims(U, I)
     n = users.numel()
+    mode = EVAL_MODES[precision]
     if out is None:
         out = torch.empty((n, k), dtype=torch.int64, device=U.device)
     flag = new_error_flag(U.device)
-    ws_bytes = lib.yr_mf_eval_topk_workspace_bytes(n, ni, int(k)) if sliced else 0
+    if sliced:
+        ws_bytes = lib.yr_mf_eval_topk_workspace_bytes(n, ni, d, int(k), mode)
+    else:
+        ws_bytes = lib.yr_mf_eval_topk_planes_bytes(ni, d) if mode else 0
     if ws_bytes < 0:
         check(int(ws_bytes), "yr_mf_eval_topk_workspace_bytes")
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=U.device) if ws_bytes else None
@@ -780,7 +789,7 @@ def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALU
                               _dev(users, torch.int64, "users"), n, d, nu, ni,
                               _opt(mask_ptr, torch.int64, "mask_ptr"), _opt(mask_idx_sorted, torch.int64, "mask_idx"),
                               float(mask_value), int(k), _dev(out, torch.int64, "out"),
-                              ws.data_ptr() if ws is not None else None, ws_bytes, flag.data_ptr(), _stream()),
+                              ws.data_ptr() if ws is not None else None, ws_bytes, mode, flag.data_ptr(), _stream()),
           "yr_mf_eval_topk")
     raise_on_flag(flag, "mf_eval_topk")
     return out
