@@ -18,7 +18,9 @@ users = torch.arange(NU, device=dev)
 buf = (ctypes.c_ulonglong * 8)()
 for rep in range(3):
     lib.yr_debug_eval_phases(buf, 1)
-    engine.mf_eval_topk(U, I, users, ptr, i.contiguous(), 10)
+    engine.mf_eval_topk(U, I, users, ptr, i.contiguous(), int(os.environ.get("YR_K", "10")),
+                        precision=os.environ.get("YR_PRECISION", "bf16x3"),
+                        prescan={"": None, "0": False, "1": True}[os.environ.get("YR_PRESCAN", "")])
     torch.cuda.synchronize()
     lib.yr_debug_eval_phases(buf, 0)
 v = list(buf)

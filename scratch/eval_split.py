@@ -21,7 +21,8 @@ def tk(name, f, n=10):
 out = {}
 for k in (10, 4, 16):
     for prec in ("f32", "bf16x3"):
-        tk(f'k={k} {prec}', lambda: out.__setitem__((k, prec), engine.mf_eval_topk(U, I, users, ptr, sidx, k, precision=prec)))
+        tk(f"k={k} {prec}", lambda: out.__setitem__((k, prec), engine.mf_eval_topk(U, I, users, ptr, sidx, k, precision=prec)))
+        tk(f"k={k} {prec} no prescan", lambda: out.__setitem__((k, prec, 0), engine.mf_eval_topk(U, I, users, ptr, sidx, k, precision=prec, prescan=False)))
 tk('k=10 bf16x3 no masks', lambda: engine.mf_eval_topk(U, I, users, None, None, 10))
 tk('k=10 bf16x3 unsliced', lambda: engine.mf_eval_topk(U, I, users, ptr, sidx, 10, sliced=False))
 a, b = out[(10, "f32")].cpu().numpy(), out[(10, "bf16x3")].cpu().numpy()
@@ -30,3 +31,6 @@ p, ix = ptr.cpu().numpy(), sidx.cpu().numpy()
 lists = [ix[p[r]:p[r + 1]] for r in range(nu)]
 nd = assert_topk_equal_up_to_near_ties(b, a, U.cpu().numpy(), I.cpu().numpy(), users.cpu().numpy(), lists, rel=2e-6)
 print('differing rows, all near-ties at 2e-6 x sum|u_d i_d|:', nd)
+for k in (10, 4, 16):
+    for prec in ("f32", "bf16x3"):
+        print(f'k={k} {prec}: prescan == no prescan:', bool((out[(k, prec)] == out[(k, prec, 0)]).all()))

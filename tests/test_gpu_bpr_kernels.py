@@ -211,6 +211,9 @@ def test_fused_eval_topk_edge_cases(device, d):
         for precision in ("bf16x3", "f32"):
             a = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, precision=precision).cpu().numpy()
             assert_topk_equal_up_to_near_ties(a, b, U, I, users, lists)
+            # with the sampling launch (here it scores the whole small catalogue): identical lists, masked tails included
+            p = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, precision=precision, prescan=True)
+            np.testing.assert_array_equal(p.cpu().numpy(), a)
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "f32"])
@@ -242,11 +245,16 @@ def test_fused_eval_catalogue_slices_equal_one_slice(device, ni, expect_slices, 
     for k in (1, 10, 16):
         planes = lib.yr_mf_eval_topk_planes_bytes(ni, d)
         assert planes == -(-ni * 6 * d // 256) * 256
-        assert lib.yr_mf_eval_topk_workspace_bytes(n, ni, d, k, 0) == n * expect_slices * k * 8
-        assert lib.yr_mf_eval_topk_workspace_bytes(n, ni, d, k, 1) == planes + n * expect_slices * k * 8
+        assert lib.yr_mf_eval_topk_workspace_bytes(n, ni, d, k, 2) == n * expect_slices * k * 8
+        assert lib.yr_mf_eval_topk_workspace_bytes(n, ni, d, k, 3) == planes + n * expect_slices * k * 8
+        gmax = -(-n * expect_slices * 128 // 256) * 256                      # prescan: 32 floats per row and part
+        assert lib.yr_mf_eval_topk_workspace_bytes(n, ni, d, k, 5) == planes + gmax + n * expect_slices * k * 8
         a = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, sliced=True, precision=precision).cpu().numpy()
         b = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, sliced=False, precision=precision).cpu().numpy()
         np.testing.assert_array_equal(a, b)
+        for prescan in (True, False):                                          # thresholds from the sampling launch
+            p = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, precision=precision, prescan=prescan)
+            np.testing.assert_array_equal(p.cpu().numpy(), a)
         c = engine.mf_recommend(t(U), t(I), t(users), t(ptr), t(idx), k, fused=False).cpu().numpy()
         assert_topk_equal_up_to_near_ties(a, c, U, I, users, lists)
         for r in range(n):
@@ -281,6 +289,8 @@ def test_fused_eval_with_item_bias(device, d, precision):
                                 precision=precision).cpu().numpy()
         np.testing.assert_array_equal(a, b)
         assert_topk_equal_up_to_near_ties(a, want, Ua, Ia, users, lists)
+        p = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, item_bias=t(bias), precision=precision, prescan=True)
+        np.testing.assert_array_equal(p.cpu().numpy(), a)
         plain = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, precision=precision).cpu().numpy()
         assert (plain != a).any()                                            # the bias matters
 
@@ -300,6 +310,9 @@ def test_fused_eval_mask_value_paths_agree(device):
     t = lambda a: torch.from_numpy(a).to(device)
     a = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), 10).cpu().numpy()
     b = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), 10, mask_value=-1.0e30).cpu().numpy()
+    for mv in (-3.40282e+38, -1.0e30):
+        p = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), 10, mask_value=mv, prescan=True).cpu().numpy()
+        np.testing.assert_array_equal(p, a)
     # the 4 unmasked items lead; the masked tail is ordered by item id in both (equal scores)
     np.testing.assert_array_equal(a, b)
     for r in range(0, n, 9):

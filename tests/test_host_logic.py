@@ -74,12 +74,17 @@ def test_argument_checks_without_gpu():
                                   0.999, 1e-8, 0.0, 0, None) == 0
     assert lib.yr_mf_eval_topk_bias(None, None, None, None, 4, 64, 10, 10, None, None, 0.0, 17, None, None, 0, 0, None,
                                     None) == -2                                                     # k > 16
-    assert lib.yr_mf_eval_topk_bias(None, None, None, None, 4, 64, 10, 10, None, None, 0.0, 10, None, None, 0, 2, None,
-                                    None) == -2                                                     # unknown mode
+    assert lib.yr_mf_eval_topk_bias(None, None, None, None, 4, 64, 10, 10, None, None, 0.0, 10, None, None, 0, 8, None,
+                                    None) == -2                                                     # unknown mode bit
+    assert lib.yr_mf_eval_topk_bias(None, None, None, None, 4, 64, 10, 10, None, None, 0.0, 10, None, None, 0, 6, None,
+                                    None) == -2                                                     # prescan off AND forced
     assert lib.yr_mf_eval_topk_planes_bytes(1000, 64) == 1000 * 6 * 64
     assert lib.yr_mf_eval_topk_planes_bytes(1000, 48) == -2
     assert lib.yr_mf_eval_topk_workspace_bytes(128, 1000, 64, 10, 1) == 1000 * 6 * 64               # one slice: planes only
     assert lib.yr_mf_eval_topk_workspace_bytes(128, 1000, 64, 10, 0) == 0
+    assert lib.yr_mf_eval_topk_workspace_bytes(128, 1000, 64, 10, 4) == 128 * 128                   # forced prescan: maxima
+    assert lib.yr_mf_eval_topk_workspace_bytes(128, 20000, 64, 10, 0) > lib.yr_mf_eval_topk_workspace_bytes(128, 20000, 64, 10, 2)
+    assert lib.yr_mf_eval_topk_workspace_bytes(128, 20000, 64, 4, 0) == lib.yr_mf_eval_topk_workspace_bytes(128, 20000, 64, 4, 2)
 
 
 def test_ops_refuse_cpu_tensors():
@@ -184,3 +189,37 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)                          # forget the cached handle for this test
     with pytest.raises(_lib.EngineError, match="not found"):
         _lib.load()
+
+
+def test_bf16x3_split_reproduces_f32_products():
+    """The arithmetic behind YR_EVAL_BF16X3 (csrc/eval_topk.hip, et_split3), restated in NumPy: three bfloat16 terms
+    (round to nearest even each time, residuals exact in f32) reproduce an f32 value to 2^-24 of its magnitude or
+    better, and the six partial products of weight >= 2^-18 give every dot product to well below the f32 rounding
+    of the same dot product (compared with the exact float64 value)."""
+    def bf16(x):                                     # f32 -> nearest-even bfloat16, returned as f32
+        b = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+        b = ((b + 0x7fff + ((b >> 16) & 1)) >> 16) << 16
+        return b.astype(np.uint32).view(np.float32)
+
+    def split3(x):
+        x1 = bf16(x)
+        r1 = (x - x1).astype(np.float32)
+        x2 = bf16(r1)
+        x3 = bf16((r1 - x2).astype(np.float32))
+        return x1, x2, x3
+
+    rs = np.random.RandomState(3)
+    x = (rs.standard_normal(20000) * np.exp(rs.uniform(-20, 20, 20000))).astype(np.float32)
+    x1, x2, x3 = split3(x)
+    assert np.all(np.abs(x.astype(np.float64) - x1 - x2.astype(np.float64) - x3) <= np.abs(x) * 2.0 ** -24)
+    U = (rs.standard_normal((64, 64)) * 0.1).astype(np.float32)
+    I = (rs.standard_normal((512, 64)) * 0.1).astype(np.float32)
+    u, i = [p.astype(np.float64) for p in split3(U)], [p.astype(np.float64) for p in split3(I)]
+    six = sum(u[a] @ i[b].T for a, b in ((0, 0), (0, 1), (1, 0), (1, 1), (0, 2), (2, 0)))
+    exact = U.astype(np.float64) @ I.astype(np.float64).T
+    scale = np.abs(U).astype(np.float64) @ np.abs(I).astype(np.float64).T        # sum_d |u_d i_d|
+    assert np.max(np.abs(six - exact) / scale) < 2.0 ** -24                      # dropped terms: x2 y3, x3 y2, x3 y3
+    f32 = (U @ I.T).astype(np.float64)                                           # what an f32 dot product rounds to
+    assert np.max(np.abs(six - exact) / scale) < np.max(np.abs(f32 - exact) / scale)
+    five = six - u[1] @ i[1].T                                                   # one product fewer is NOT enough
+    assert np.max(np.abs(five - exact) / scale) > 2.0 ** -22

@@ -26,6 +26,8 @@
 // chip at Yelp2018 size (one wave per 32 users alone is < 1 wave per SIMD); each slice keeps its own
 // top-k per user and a second small kernel merges the S sorted partial lists.
 // Order: score descending, item id ascending among equal scores (as csrc/topk.hip).
+#include <algorithm>
+
 #include "common.h"
 
 namespace yr {
@@ -139,6 +141,12 @@ __global__ __launch_bounds__(kBlock) void et_split_rows_kernel(const float* __re
   planes[(row * 3 + 2) * D8 + c] = p3;
 }
 
+// items per LDS stage: 64 where three workgroups per CU fit with it (f32; SPLIT at D <= 32), else 32 — except SPLIT
+// at D = 64 with 16-entry lists, whose registers allow two workgroups per CU either way
+__host__ __device__ constexpr int et_chunk_items(int D, int KK, bool split) {
+  return !split ? kEtChunkItems : (D <= 32 ? 64 : (D == 64 && KK > 10 ? 64 : YR_ET_SPLIT_CHUNK));
+}
+
 // BIAS: score = <user, item> + item_bias[item] — the decoder of CDAE, z . W_o[i] + b_o[i] (models/cdae.py:52), whose
 // sigmoid is monotone, so the top-k of the pre-activations is the top-k of the predictions.  The bias enters as
 // the initial value of the MFMA accumulator (staged through LDS with the item chunk): no extra instruction per score.
@@ -149,18 +157,24 @@ __global__ __launch_bounds__(kBlock) void et_split_rows_kernel(const float* __re
 // f32 by v_mfma_f32_32x32x16_bf16: 6 x 4 instructions of 32 cycles per 32-item tile at D = 64 against 32 of 64 cycles
 // (v_mfma_f32_32x32x2_f32).  The accumulator layout is the same, so is everything after it.  The items arrive
 // pre-split (et_split_rows_kernel, `I` is then the plane table), the users are split once into registers.
-template <int D, int KK, bool BIAS, bool SPLIT>
+//
+// PRESCAN (a launch of its own before the sweep, `parts` workgroups per 128 users): the same scores for a strided
+// sample of the stages only (every chunk_stride-th, dealt round-robin to the parts), and per lane the running maximum
+// of each of its 16 accumulator registers — 16 disjoint groups of items, 32 per user and part, no candidates, no
+// lists.  Masked items count with the mask value, as in the sweep.  The sweep's prologue reads the 32 x parts group
+// maxima of its user: their KK-th largest is reached by KK different items, so it is a lower bound of the user's
+// KK-th best score over the whole catalogue, and every list of the user (both half-waves, every slice) starts with
+// a threshold just below it instead of -inf.  What the lists then never see could not have ended in the top k.
+template <int D, int KK, bool BIAS, bool SPLIT, bool PRESCAN>
 __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
     const float* __restrict__ U, const void* __restrict__ I_any, const float* __restrict__ item_bias,
     const int64_t* __restrict__ users, int64_t nrows,
     int64_t num_users, int num_items, const int64_t* __restrict__ mask_ptr, const int64_t* __restrict__ mask_idx,
     float mask_value, int k, int64_t* __restrict__ out, TopEntry* __restrict__ partial, int items_per_slice,
-    int32_t* __restrict__ err_flag) {
+    float* __restrict__ gmax, int parts, int chunk_stride, int32_t* __restrict__ err_flag) {
   constexpr int HALF = D / 2;
   constexpr int KB = D / 16;                                      // SPLIT: 16-deep matrix instructions per plane pair
-  // items per LDS stage: 64 where three workgroups per CU fit with it (f32; SPLIT at D <= 32), else 32 — except
-  // SPLIT at D = 64 with 16-entry lists, whose registers allow two workgroups per CU either way
-  constexpr int CH = !SPLIT ? kEtChunkItems : (D <= 32 ? 64 : (D == 64 && KK > 10 ? 64 : YR_ET_SPLIT_CHUNK));
+  constexpr int CH = et_chunk_items(D, KK, SPLIT);                // items per LDS stage
   // bytes per staged item: D + 4 floats, or three bf16 planes + 16 (an odd number of 16-byte units either way:
   // the 32 rows of a ds_read_b128 fall into different banks)
   constexpr int ROWB = SPLIT ? 6 * D + 16 : 4 * (D + 4);
@@ -174,8 +188,11 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const int i = lane & 31, h = lane >> 5;
   const int64_t row = (int64_t)blockIdx.x * kEtUsers + wave * kEtUsersPerWave + i;   // this lane's user row
-  const int item_lo = blockIdx.y * items_per_slice;  // this workgroup's slice of the catalogue
-  const int item_hi = min(num_items, item_lo + items_per_slice);
+  // this workgroup's slice of the catalogue, stage after stage; PRESCAN: the stages blockIdx.y, blockIdx.y + parts,
+  // ... of the sample
+  const int64_t step = PRESCAN ? (int64_t)parts * chunk_stride * CH : CH;
+  const int item_lo = PRESCAN ? blockIdx.y * chunk_stride * CH : blockIdx.y * items_per_slice;
+  const int item_hi = PRESCAN ? num_items : min(num_items, item_lo + items_per_slice);
 
   // B operand: this lane's half of its user's row (zeros for rows beyond the input / bad ids) — f32: dims
   // [h D/2, (h+1) D/2); SPLIT: dims 16 kb + 8 h + j of every 16-deep block kb, three planes
@@ -213,7 +230,35 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
   int32_t Li[KK];
 #pragma unroll
   for (int e = 0; e < KK; ++e) { Ls[e] = ok ? -INFINITY : INFINITY; Li[e] = 0x7fffffff; }   // +inf: nothing ever enters
-  float tau = Ls[KK - 1];
+  float tau0 = -INFINITY;                            // the floor of the threshold: from the prescan, if there was one
+  if (!PRESCAN && gmax && ok) {
+    float T[KK];                                     // the KK largest group maxima of this lane's user, descending
+#pragma unroll
+    for (int e = 0; e < KK; ++e) T[e] = -INFINITY;
+    const float4* g4 = reinterpret_cast<const float4*>(gmax + row * parts * 32);
+    for (int q = 0; q < parts * 8; ++q) {
+      const float4 g = g4[q];
+      const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = gv[j];
+#pragma unroll
+        for (int e = 0; e < KK; ++e) {
+          const bool sw = v > T[e];
+          const float t = T[e];
+          T[e] = sw ? v : t;
+          v = sw ? t : v;
+        }
+      }
+    }
+    // strictly below the bound (scores equal to it must pass the strict test); -FLT_MAX and -inf give -inf
+    const float b = T[KK - 1];
+    tau0 = b < INFINITY ? b - fmaxf(fabsf(b) * 1.0e-6f, 1.0e-30f) : 3.0e38f;
+  }
+  float tau = fmaxf(Ls[KK - 1], tau0);
+  float gm[PRESCAN ? 16 : 1];                        // PRESCAN: running maxima of the 16 accumulator registers
+#pragma unroll
+  for (int e = 0; e < (PRESCAN ? 16 : 1); ++e) gm[e] = -INFINITY;
   int cnt = 0;
   const bool lazy_mask = mask_value <= -3.0e38f;     // uniform
   // the next TWO masked item ids stay in registers: the load that refills the second one is issued
@@ -236,7 +281,7 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
       et_bubble<KK>(Ls, Li, cs, ci, live);
     }
     cnt = 0;
-    tau = Ls[KK - 1];
+    tau = fmaxf(Ls[KK - 1], tau0);
   };
 
   // register staging of the item chunks: the loads of chunk c+1 are issued before the tiles of
@@ -269,9 +314,9 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
   stash(s_items[0], 0);
   __syncthreads();
   int cur = 0;
-  for (int c0 = item_lo; c0 < item_hi; c0 += CH) {
-    const bool more = c0 + CH < item_hi;
-    if (more) fetch(c0 + CH);                        // lands in the other buffer at the end of this chunk
+  for (int c0 = item_lo; c0 < item_hi; c0 += (int)step) {
+    const bool more = c0 + step < item_hi;
+    if (more) fetch(c0 + (int)step);                 // lands in the other buffer at the end of this chunk
     const unsigned char* chunk = s_items[cur];
 
 #pragma unroll 1
@@ -327,6 +372,18 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
 #ifdef YR_ET_EXP_NOMASK      // timing experiment only (wrong results): the mask lists are ignored
       next_masked = 0x7fffffff;
 #endif
+      if constexpr (PRESCAN) {
+        // the sample skips most of the catalogue: jump over the entries below this tile eight at a time (the walk
+        // below is one dependent load per entry)
+        if (next_masked < item0) {
+          const int64_t before = m_cur;
+          while (m_cur + 8 < m_end && (int)mask_idx[m_cur + 8] < item0) m_cur += 8;
+          if (m_cur != before) {
+            next_masked = (int)mask_idx[m_cur];
+            after_next = m_cur + 1 < m_end ? (int)mask_idx[m_cur + 1] : 0x7fffffff;
+          }
+        }
+      }
       while (next_masked < item0 + 32) {
         if (next_masked >= item0) bits |= 1u << (next_masked - item0);
         ++m_cur;
@@ -340,7 +397,7 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
       const long long t_c = ET_CLK();
       ph_mask += t_c - t_b;
       const uint32_t mine = bits >> (4 * h);
-      if (!lazy_mask && __ballot(bits != 0) != 0ull) {
+      if ((PRESCAN || !lazy_mask) && __ballot(bits != 0) != 0ull) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
           if ((mine >> ((reg & 3) + 8 * (reg >> 2))) & 1u) acc[reg] = mask_value;
@@ -351,11 +408,15 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
         for (int reg = 0; reg < 16; ++reg)
           if ((beyond >> ((reg & 3) + 8 * (reg >> 2))) & 1u) acc[reg] = -INFINITY;   // not an item
       }
+      if constexpr (PRESCAN) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) gm[reg] = fmaxf(gm[reg], acc[reg]);
+      }
       // ---- candidates -> private buffer.  Strict comparison is exact: a lane meets its items in
       // ascending id order, so a later score EQUAL to the threshold loses the tie anyway; it also
       // keeps the -inf of the rows beyond the slice out.
 #pragma unroll
-      for (int half = 0; half < 16 / kEtCheckEvery; ++half) {
+      for (int half = 0; half < (PRESCAN ? 0 : 16 / kEtCheckEvery); ++half) {
 #pragma unroll
         for (int q = 0; q < kEtCheckEvery; ++q) {
           const int reg = half * kEtCheckEvery + q;
@@ -390,6 +451,14 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
     __syncthreads();
     ph_sync += ET_CLK() - t_s;
     cur ^= 1;
+  }
+  if constexpr (PRESCAN) {
+    if (row < nrows) {
+      float4* g4 = reinterpret_cast<float4*>(gmax + (row * parts + blockIdx.y) * 32 + 16 * h);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g4[q] = make_float4(gm[4 * q], gm[4 * q + 1], gm[4 * q + 2], gm[4 * q + 3]);
+    }
+    return;
   }
   flush();
 #ifdef YR_ET_STAMPS
@@ -476,22 +545,96 @@ static int et_slices(int64_t nrows, int64_t num_items) {
   return (int)(S < 1 ? 1 : S);
 }
 
-// SPLIT mode: the item planes come first in the workspace, the partial lists of the slices after them
+// Workspace, in this order: the item planes (YR_EVAL_BF16X3), the group maxima of the prescan, the partial lists
 static int64_t et_plane_bytes(int64_t num_items, int D) { return (num_items * 6 * D + 255) / 256 * 256; }
+static int64_t et_gmax_bytes(int64_t nrows, int parts) { return (nrows * parts * 32 * 4 + 255) / 256 * 256; }
+
+#ifndef YR_ET_SAMPLE_ITEMS
+#define YR_ET_SAMPLE_ITEMS 4096
+#endif
+// The prescan scores an eighth of the catalogue per user, 4,096 items at most (a prescan stage costs about what a
+// stage of the sweep costs: Yelp2018 size, sweep alone -> with 1,024 / 2,048 / 4,096 sampled items: k = 10
+// 1.20 -> 1.19 / 1.16 / 1.11 ms, k = 16 2.63 -> 2.44 / 2.30 / 2.13 ms, k = 4 0.88 -> 0.92 ms whatever the sample).
+// Worth its launch from 16,384 items and lists of more than four entries.
+constexpr int kEtSampleItems = YR_ET_SAMPLE_ITEMS;
+constexpr int64_t kEtPrescanMinItems = 16384;
+static bool et_prescan_wanted(int64_t num_items, int k, int mode) {
+  if (mode & YR_EVAL_NO_PRESCAN) return false;
+  return (mode & YR_EVAL_FORCE_PRESCAN) || (num_items >= kEtPrescanMinItems && k > 4);
+}
+static bool et_mode_ok(int mode) {
+  return (mode & ~(YR_EVAL_BF16X3 | YR_EVAL_NO_PRESCAN | YR_EVAL_FORCE_PRESCAN)) == 0 &&
+         (mode & (YR_EVAL_NO_PRESCAN | YR_EVAL_FORCE_PRESCAN)) != (YR_EVAL_NO_PRESCAN | YR_EVAL_FORCE_PRESCAN);
+}
+static bool et_dim_ok(int D) { return D == 16 || D == 32 || D == 64 || D == 128; }
 
 extern "C" int64_t yr_mf_eval_topk_planes_bytes(int64_t num_items, int D) {
-  if (num_items <= 0 || (D != 16 && D != 32 && D != 64 && D != 128)) return YR_ERR_BADARG;
+  if (num_items <= 0 || !et_dim_ok(D)) return YR_ERR_BADARG;
   return et_plane_bytes(num_items, D);
 }
 
 extern "C" int64_t yr_mf_eval_topk_workspace_bytes(int64_t nrows, int64_t num_items, int D, int k, int mode) {
-  if (nrows < 0 || num_items <= 0 || k <= 0 || k > kEtMaxK || (mode != YR_EVAL_F32 && mode != YR_EVAL_BF16X3) ||
-      (D != 16 && D != 32 && D != 64 && D != 128))
-    return YR_ERR_BADARG;
+  if (nrows < 0 || num_items <= 0 || k <= 0 || k > kEtMaxK || !et_mode_ok(mode) || !et_dim_ok(D)) return YR_ERR_BADARG;
   const int S = et_slices(nrows, num_items);
-  return (mode == YR_EVAL_BF16X3 ? et_plane_bytes(num_items, D) : 0) +
+  return ((mode & YR_EVAL_BF16X3) ? et_plane_bytes(num_items, D) : 0) +
+         (et_prescan_wanted(num_items, k, mode) ? et_gmax_bytes(nrows, S) : 0) +
          (S > 1 ? nrows * S * k * (int64_t)sizeof(TopEntry) : 0);
 }
+
+namespace {
+struct EtArgs {
+  const float* U;
+  const void* items;
+  const float* item_bias;
+  const int64_t* users;
+  int64_t nrows, num_users;
+  int num_items;
+  const int64_t *mask_ptr, *mask_idx;
+  float mask_value;
+  int k;
+  int64_t* out;
+  TopEntry* partial;
+  int per;
+  float* gmax;          // NULL: no prescan
+  int parts;
+  int32_t* err_flag;
+  unsigned row_blocks, slices;
+};
+
+template <int DD, int KK, bool BB, bool SS, bool PP>
+void et_launch_one(const EtArgs& a, dim3 grid, int chunk_stride, hipStream_t s) {
+  hipLaunchKernelGGL((mf_eval_topk_kernel<DD, KK, BB, SS, PP>), grid, dim3(kEtThreads), 0, s, a.U, a.items, a.item_bias,
+                     a.users, a.nrows, a.num_users, a.num_items, a.mask_ptr, a.mask_idx, a.mask_value, a.k, a.out,
+                     a.partial, a.per, a.gmax, a.parts, chunk_stride, a.err_flag);
+}
+
+template <int DD, bool BB, bool SS>
+void et_launch(const EtArgs& a, hipStream_t s) {
+  if (a.gmax) {
+    // every stride-th stage of the catalogue, dealt to `parts` workgroups
+    constexpr int CHP = et_chunk_items(DD, 4, SS);
+    const int chunks = (a.num_items + CHP - 1) / CHP;
+    const int sample = std::min(kEtSampleItems, std::max(CHP, a.num_items / 8));
+    const int stride = std::max(1, chunks / std::max(1, sample / CHP));
+    et_launch_one<DD, 4, BB, SS, true>(a, dim3(a.row_blocks, (unsigned)a.parts), stride, s);
+  }
+  const dim3 grid(a.row_blocks, a.slices);
+  if (a.k <= 4) et_launch_one<DD, 4, BB, SS, false>(a, grid, 0, s);
+  else if (a.k <= 10) et_launch_one<DD, 10, BB, SS, false>(a, grid, 0, s);
+  else et_launch_one<DD, 16, BB, SS, false>(a, grid, 0, s);
+}
+
+template <int DD>
+void et_launch_d(const EtArgs& a, bool split, hipStream_t s) {
+  if (a.item_bias) {
+    if (split) et_launch<DD, true, true>(a, s);
+    else et_launch<DD, true, false>(a, s);
+  } else {
+    if (split) et_launch<DD, false, true>(a, s);
+    else et_launch<DD, false, false>(a, s);
+  }
+}
+}  // namespace
 
 extern "C" int yr_mf_eval_topk_bias(const float* U, const float* I, const float* item_bias, const int64_t* users,
                                     int64_t nrows, int D, int64_t num_users, int64_t num_items,
@@ -499,63 +642,63 @@ extern "C" int yr_mf_eval_topk_bias(const float* U, const float* I, const float*
                                     int64_t* out, void* workspace, int64_t workspace_bytes, int mode, int32_t* err_flag,
                                     void* stream) {
   if (nrows < 0 || num_users <= 0 || num_items <= 0 || num_items > 0x7ffffff0 || k <= 0 || k > kEtMaxK ||
-      (mode != YR_EVAL_F32 && mode != YR_EVAL_BF16X3) || workspace_bytes < 0)
+      !et_mode_ok(mode) || workspace_bytes < 0)
     return YR_ERR_BADARG;
-  if (D != 16 && D != 32 && D != 64 && D != 128) return YR_ERR_UNSUPPORTED;
+  if (!et_dim_ok(D)) return YR_ERR_UNSUPPORTED;
   if (nrows == 0) return 0;
   if (!U || !I || !users || !out || (mask_ptr && !mask_idx)) return YR_ERR_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  const bool split = mode == YR_EVAL_BF16X3;
-  const void* items = I;
+  const bool split = (mode & YR_EVAL_BF16X3) != 0;
+  char* ws = static_cast<char*>(workspace);
+  if (!ws) workspace_bytes = 0;
+  EtArgs a{};
+  a.U = U;
+  a.items = I;
   if (split) {
     const int64_t pb = et_plane_bytes(num_items, D);
-    if (!workspace || workspace_bytes < pb) return YR_ERR_BADARG;             // the planes are not optional
+    if (workspace_bytes < pb) return YR_ERR_BADARG;                            // the planes are not optional
     const int64_t groups = num_items * (D / 8);
     hipLaunchKernelGGL(et_split_rows_kernel, dim3((unsigned)((groups + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, I,
-                       groups, D / 8, static_cast<uint4*>(workspace));
-    items = workspace;
-    workspace = static_cast<char*>(workspace) + pb;
+                       groups, D / 8, reinterpret_cast<uint4*>(ws));
+    a.items = ws;
+    ws += pb;
     workspace_bytes -= pb;
   }
   int S = et_slices(nrows, num_items);
-  if (S > 1 && (!workspace || workspace_bytes < nrows * S * k * (int64_t)sizeof(TopEntry))) S = 1;   // no room: one slice
+  if (et_prescan_wanted(num_items, k, mode) && workspace_bytes >= et_gmax_bytes(nrows, S)) {   // no room: no prescan
+    a.gmax = reinterpret_cast<float*>(ws);
+    a.parts = S;
+    ws += et_gmax_bytes(nrows, S);
+    workspace_bytes -= et_gmax_bytes(nrows, S);
+  }
+  if (S > 1 && workspace_bytes < nrows * S * k * (int64_t)sizeof(TopEntry)) S = 1;          // no room: one slice
   int per = (int)((num_items + S - 1) / S);
   per = (per + 31) / 32 * 32;                          // whole 32-item tiles
   S = (int)((num_items + per - 1) / per);
-  TopEntry* partial = S > 1 ? static_cast<TopEntry*>(workspace) : nullptr;
-  const dim3 grid((unsigned)((nrows + kEtUsers - 1) / kEtUsers), (unsigned)S);
-#define YR_ET_LAUNCH_B(DD, KK, BB, SS)                                                                              \
-  hipLaunchKernelGGL((mf_eval_topk_kernel<DD, KK, BB, SS>), grid, dim3(kEtThreads), 0, s, U, items, item_bias, users, \
-                     nrows, num_users, (int)num_items, mask_ptr, mask_idx, mask_value, k, out, partial, per, err_flag)
-#define YR_ET_LAUNCH(DD, KK)                                 \
-  do {                                                       \
-    if (item_bias) {                                         \
-      if (split) YR_ET_LAUNCH_B(DD, KK, true, true);         \
-      else YR_ET_LAUNCH_B(DD, KK, true, false);              \
-    } else {                                                 \
-      if (split) YR_ET_LAUNCH_B(DD, KK, false, true);        \
-      else YR_ET_LAUNCH_B(DD, KK, false, false);             \
-    }                                                        \
-  } while (0)
-#define YR_ET_CASE(DD)                                     \
-  case DD:                                                 \
-    if (k <= 4) YR_ET_LAUNCH(DD, 4);                       \
-    else if (k <= 10) YR_ET_LAUNCH(DD, 10);                \
-    else YR_ET_LAUNCH(DD, 16);                             \
-    break
+  a.item_bias = item_bias;
+  a.users = users;
+  a.nrows = nrows;
+  a.num_users = num_users;
+  a.num_items = (int)num_items;
+  a.mask_ptr = mask_ptr;
+  a.mask_idx = mask_idx;
+  a.mask_value = mask_value;
+  a.k = k;
+  a.out = out;
+  a.partial = S > 1 ? reinterpret_cast<TopEntry*>(ws) : nullptr;
+  a.per = per;
+  a.err_flag = err_flag;
+  a.row_blocks = (unsigned)((nrows + kEtUsers - 1) / kEtUsers);
+  a.slices = (unsigned)S;
   switch (D) {
-    YR_ET_CASE(16);
-    YR_ET_CASE(32);
-    YR_ET_CASE(64);
-    YR_ET_CASE(128);
-    default: return YR_ERR_UNSUPPORTED;
+    case 16: et_launch_d<16>(a, split, s); break;
+    case 32: et_launch_d<32>(a, split, s); break;
+    case 64: et_launch_d<64>(a, split, s); break;
+    default: et_launch_d<128>(a, split, s); break;
   }
-#undef YR_ET_CASE
-#undef YR_ET_LAUNCH
-#undef YR_ET_LAUNCH_B
   if (S > 1)
     hipLaunchKernelGGL(mf_eval_merge_kernel, dim3((unsigned)((nrows + kBlock - 1) / kBlock)), dim3(kBlock), 0, s,
-                       partial, nrows, S, k, out);
+                       a.partial, nrows, S, k, out);
   return launch_status();
 }
 

@@ -763,24 +763,31 @@ EVAL_MODES = {"f32": 0, "bf16x3": 1}          # YR_EVAL_F32 / YR_EVAL_BF16X3 (in
 
 
 def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALUE, out=None, sliced=True,
-                 item_bias=None, precision="bf16x3"):
+                 item_bias=None, precision="bf16x3", prescan=None):
     """Fused full-catalogue scoring + mask + top-k (no score matrix).  ``mask_idx_sorted``: CSR mask
     lists with ascending ids inside each row (see :func:`sort_mask_rows`).  ``sliced=False`` withholds
     the room for the partial lists, i.e. forces the one-slice form of the kernel (tests).  ``item_bias``: scores
     U[u] . I[j] + item_bias[j] (the CDAE decoder before its sigmoid).  ``precision``: "bf16x3" — f32 scores from
     three-term bfloat16 splits of both operands on the bf16 matrix instructions (six partial products, error below
-    the f32 rounding of a product) — or "f32", the f32 matrix instruction itself."""
+    the f32 rounding of a product) — or "f32", the f32 matrix instruction itself.  ``prescan``: None = the
+    library's rule (catalogues of 16,384 items and more), False / True = never / always run the sampling launch that
+    gives the lists their starting thresholds (same result either way; ``sliced=False`` implies False)."""
     lib = _lib.load()
     nu, ni, d = _table_dims(U, I)
     n = users.numel()
     mode = EVAL_MODES[precision]
+    planes_only = lib.yr_mf_eval_topk_planes_bytes(ni, d) if mode else 0
+    if prescan is False or not sliced:
+        mode |= 2                                   # YR_EVAL_NO_PRESCAN
+    elif prescan:
+        mode |= 4                                   # YR_EVAL_FORCE_PRESCAN
     if out is None:
         out = torch.empty((n, k), dtype=torch.int64, device=U.device)
     flag = new_error_flag(U.device)
     if sliced:
         ws_bytes = lib.yr_mf_eval_topk_workspace_bytes(n, ni, d, int(k), mode)
     else:
-        ws_bytes = lib.yr_mf_eval_topk_planes_bytes(ni, d) if mode else 0
+        ws_bytes = planes_only
     if ws_bytes < 0:
         check(int(ws_bytes), "yr_mf_eval_topk_workspace_bytes")
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=U.device) if ws_bytes else None

@@ -143,7 +143,8 @@ class CDAETrainer(BaseTrainer):
         (sp, si), (ap, ai) = item_lists["seen"], item_lists["actual"]
         mask_value = engine.MASK_VALUE if model._output_act == engine.ACT_SIGMOID else 0.0
         top = engine.mf_eval_topk(Z, Wo, torch.arange(model.num_users, device=dev), sp, si, self.cfg.top_n,
-                                  mask_value=mask_value, item_bias=bo)
+                                  mask_value=mask_value, item_bias=bo,
+                                  precision=self.cfg.get("eval_precision", "bf16x3"))
         model.check_indices()
         return engine.rank_metrics(top, ap, ai)[4:10]
 

@@ -276,7 +276,9 @@ class MFTrainer(BaseTrainer):
         """Top-``top_n`` item ids per user, masked items excluded ([n_users, top_n] int64, device)."""
         U, I = self.model.user_embedding.weight.detach(), self.model.item_embedding.weight.detach()
         if self.cfg.top_n <= 16:                          # fused scores + mask + top-k; masks are pre-sorted
-            return engine.mf_eval_topk(U, I, users.contiguous(), mask_ptr, mask_idx, self.cfg.top_n)
+            # cfg.eval_precision: "bf16x3" (default; f32 scores from three-term bf16 splits) or "f32"
+            return engine.mf_eval_topk(U, I, users.contiguous(), mask_ptr, mask_idx, self.cfg.top_n,
+                                       precision=self.cfg.get("eval_precision", "bf16x3"))
         return engine.mf_recommend(U, I, users, mask_ptr, mask_idx, self.cfg.top_n, fused=False)
 
     def evaluate(self, eval_data, mode='valid') -> tuple:
