@@ -9,5 +9,5 @@ for v in "$@"; do
   (cd ../.. && python3 scratch/eval_phases.py) || exit 1
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form $v -c eval_topk.hip -o eval_topk.o || exit 1
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libyelprec_engine.so *.o || exit 1
-  (cd ../.. && python3 scratch/eval_split.py 2>&1 | grep -E "k=10 (f32|bf16x3) [0-9]|k=4 bf|k=16 bf") || exit 1
+  (cd ../.. && python3 scratch/eval_split.py 2>&1 | grep -E "k=(4|10|16) bf16x3 [0-9n]") || exit 1
 done
