@@ -356,3 +356,36 @@ def test_full_catalogue_eval_properties(device):
     pp, pi = pptr.cpu().numpy(), pidx.cpu().numpy()
     actual = [pi[pp[r]:pp[r + 1]].tolist() for r in range(n)]
     np.testing.assert_allclose(got, metric.ranking_metrics(actual, fused.cpu().numpy().tolist(), k), rtol=1e-12)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+def test_fused_eval_prescan_with_a_mask_value_inside_the_score_range(device, precision):
+    """Mask value 0 (CDAE's multiply-mask on outputs that are not sigmoids): masked items keep a score that can
+    belong to the top k.  The prescan counts them with that value, like the sweep: lists identical with and without
+    it, and equal to float64 scores with the masked entries set to 0 (up to near-ties).  Catalogue large enough for
+    several slices and for the prescan to sample (stride > 1), users with most of the catalogue masked included."""
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(31)
+    nu, ni, n, d, k = 120, 20011, 101, 64, 10
+    U, I = _tables(rs, nu, ni, d)
+    users = rs.randint(0, nu, size=n).astype(np.int64)
+    lists = [np.sort(rs.choice(ni, size=(ni - 7 if r % 11 == 0 else rs.randint(0, 4000)), replace=False)) for r in range(n)]
+    ptr = np.zeros(n + 1, np.int64); ptr[1:] = np.cumsum([len(l) for l in lists])
+    idx = np.concatenate(lists).astype(np.int64)
+    t = lambda a: torch.from_numpy(a).to(device)
+    a = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, mask_value=0.0, precision=precision,
+                            prescan=True).cpu().numpy()
+    b = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, mask_value=0.0, precision=precision,
+                            prescan=False).cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+    c = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, mask_value=0.0, precision=precision).cpu().numpy()
+    np.testing.assert_array_equal(c, a)                                       # the library's own rule (>= 16,384 items)
+    exact = U[users].astype(np.float64) @ I.astype(np.float64).T
+    for r in range(n):
+        exact[r, lists[r]] = 0.0
+    want = np.argsort(-exact, axis=1, kind="stable")[:, :k]
+    differing = np.flatnonzero((a != want).any(axis=1))
+    for r in differing:                                                       # near-ties only (f32 vs float64 scores)
+        tol = 2e-5 * float(np.abs(I[np.r_[a[r], want[r]]].astype(np.float64)) @ np.abs(U[users[r]].astype(np.float64))).max() + 1e-30
+        assert np.all(np.abs(np.sort(exact[r, a[r]]) - np.sort(exact[r, want[r]])) <= tol), r
+    assert len(differing) <= n // 10
