@@ -17,7 +17,8 @@ trainer = CDAETrainer(cfg, NI, NU)
 form = sys.argv[2] if len(sys.argv) > 2 else "lists"
 print("batches as", form)
 valid = CDAEBatchLoader(data, "valid", batch_size=B, neg_times=5, seed=4, lists=form == "lists")
-test = CDAEBatchLoader(data, "test", batch_size=B, seed=5, lists=form == "lists")
+TB = int(sys.argv[3]) if len(sys.argv) > 3 else B            # rows per evaluation batch (the result does not depend on it)
+test = CDAEBatchLoader(data, "test", batch_size=TB, seed=5, lists=form == "lists")
 for name, fn, n in (("validate", lambda: trainer.validate(valid), len(valid)), ("evaluate", lambda: trainer.evaluate(test), len(test))):
     fn()
     torch.cuda.synchronize()

@@ -675,6 +675,10 @@ def test_list_route_of_validate_and_evaluate_equals_dense_route(device, tmp_path
         else:                                                                    # a float near-tie at rank 10 / 11
             got, want = trainer.evaluate(as_lists), trainer.evaluate(dense)      # may move one membership
             np.testing.assert_allclose(got, want, atol=1e-3, rtol=0)
+            # the rows per evaluation batch do not enter the result (train.py builds the test loader with larger ones)
+            for rows in (7, nu):
+                again = trainer.evaluate(CDAEBatchLoader(data, mode, batch_size=rows, neg_times=3, seed=7, lists=True))
+                assert tuple(again) == tuple(got)
     # the lists behind the metrics: fused all-user top-10 against the per-batch masked top-k of the dense prediction
     model = trainer.model.eval()
     users = torch.arange(nu, device=device)

