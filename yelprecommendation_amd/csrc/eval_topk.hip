@@ -1,4 +1,4 @@
-// Fused evaluation for gfx950 (MI355X): full-catalogue scores on the f32 matrix cores with the
+// Fused evaluation for gfx950 (MI355X): full-catalogue f32 scores on the matrix cores with the
 // train-item mask and the top-k selection in the GEMM epilogue — the U x I score matrix (4.8 GB at
 // Yelp2018 size) is never written.
 //
@@ -7,9 +7,11 @@
 //   pred[mask_items] = -3.40282e+38; argpartition; argsort         (trainers/mf_trainer.py:163-178)
 //
 // Workgroup = 4 waves = 128 eval users (32 per wave) x one SLICE of the catalogue (blockIdx.y).
-// The users are the B operand of v_mfma_f32_32x32x2_f32 (exact f32), held in registers for the
-// whole kernel; the items are the A operand, staged through LDS in chunks shared by the four waves
-// (pitch D+4, next chunk prefetched into registers under the MFMAs).  In the 32x32 accumulator
+// The users are the B operand of the matrix instruction — v_mfma_f32_32x32x2_f32 on the f32 rows, or
+// v_mfma_f32_32x32x16_bf16 on three-term bf16 splits of both operands (SPLIT, below: the same f32 scores
+// at 3/8 of the matrix-core cycles) —, held in registers for the whole kernel; the items are the A operand,
+// staged through LDS in stages shared by the four waves (row pitch an odd number of 16-byte units, next
+// stage prefetched into registers under the MFMAs).  In the 32x32 accumulator
 // lane (i, h) then holds the scores of ITS OWN user i for 16 items of the tile (the other half-wave
 // holds the other 16), so selection needs no cross-lane traffic:
 //   * every lane keeps a private sorted top-KK list (score, item) in registers;
@@ -22,10 +24,12 @@
 //   * at the end the two half-waves exchange their lists with shuffles and merge them.
 // Masks: each lane walks its user's mask list (CSR, item ids ASCENDING) with a private cursor and
 // turns the masked items of the current tile into a 32-bit word.
-// Slicing the catalogue (S slices -> S x as many workgroups, two resident per CU) is what fills the
+// Slicing the catalogue (S slices -> S x as many workgroups, three resident per CU) is what fills the
 // chip at Yelp2018 size (one wave per 32 users alone is < 1 wave per SIMD); each slice keeps its own
-// top-k per user and a second small kernel merges the S sorted partial lists.
+// top-k per user and a second small kernel merges the S sorted partial lists.  A PRESCAN launch (below)
+// gives all lists of a user a common starting threshold.
 // Order: score descending, item id ascending among equal scores (as csrc/topk.hip).
+// Built with -mllvm -amdgpu-mfma-vgpr-form (csrc/Makefile): accumulators in VGPRs.
 #include <algorithm>
 
 #include "common.h"
@@ -42,9 +46,10 @@ constexpr int kEtUsers = kEtWaves * kEtUsersPerWave;   // 128 per workgroup
 constexpr int kEtChunkItems = 64;                      // items per LDS stage (two 32-item tiles)
 constexpr int kEtMaxK = 16;
 // Candidate buffers of 8 slots (flush when some lane holds more than 4, checked after every 4 accumulator
-// registers) and three catalogue slices at Yelp2018 size leave room for three workgroups per CU: 2.08 -> 1.94 ms
-// (16 slots / check every 8 / two per CU before; four per CU — 32-item stages, four slices — was slower, 2.37 ms:
-// every slice has to warm up its own thresholds).
+// registers) and three catalogue slices at Yelp2018 size leave room for three workgroups per CU (f32 form:
+// 2.08 -> 1.94 ms; 16 slots / check every 8 / two per CU before; 6 to 13 slots make no difference in the split form).
+// YR_ET_SPLIT_CHUNK: items per LDS stage of the split form at D = 64 (32: 25.6 KB of stages, three workgroups
+// per CU, 1.11 ms; 64: two per CU, 1.70 ms).
 #ifndef YR_ET_FLUSH_AT
 #define YR_ET_FLUSH_AT 4
 #endif
