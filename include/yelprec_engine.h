@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 26
+#define YR_ENGINE_VERSION 27
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -430,13 +430,21 @@ int yr_mf_scores_gemm(const float *U, const float *I, const int64_t *users, int6
  * planes); skipped without room. */
 #define YR_EVAL_NO_PRESCAN 2
 #define YR_EVAL_FORCE_PRESCAN 4   /* prescan whatever the catalogue size (tests) */
+/* hint (may be NULL): int64 [nrows, k], any k item ids per row — typically `out` of the previous evaluation of the
+ * same rows (the same buffer may be passed as hint and out).  k DIFFERENT items whose scores are all >= b prove that
+ * the row's k-th best score is >= b, so the lists start from the smallest hint score (lowered by more than f32
+ * rounding can account for; masked hints count with mask_value) instead of from -inf or from the prescan's bound,
+ * and the prescan launch is skipped.  Rows whose hint holds an id outside [0, num_items) — e.g. the -1 padding of a
+ * short list — or a repeated id get no bound.  The result never depends on the hint; a model that moved little since
+ * the hint was computed keeps most of its top-k, and the sweep then inserts an order of magnitude fewer candidates.
+ * Needs 4 bytes per row of workspace (after the planes; always part of yr_mf_eval_topk_workspace_bytes). */
 int64_t yr_mf_eval_topk_planes_bytes(int64_t num_items, int D);
 int64_t yr_mf_eval_topk_workspace_bytes(int64_t nrows, int64_t num_items, int D, int k, int mode);
 int yr_mf_eval_topk(const float *U, const float *I, const int64_t *users, int64_t nrows, int D,
                     int64_t num_users, int64_t num_items,
                     const int64_t *mask_ptr, const int64_t *mask_idx, float mask_value,
                     int k, int64_t *out, void *workspace, int64_t workspace_bytes, int mode,
-                    int32_t *err_flag, void *stream);
+                    const int64_t *hint, int32_t *err_flag, void *stream);
 /* yr_mf_eval_topk_bias: the same with scores U[users[r]] . I[j] + item_bias[j] (item_bias NULL: yr_mf_eval_topk).
  *   The evaluation of CDAE (trainers/cdae_trainer.py:90-144) for ALL users at once: U = the hidden rows z
  *   [users, H], I = output_layer.weight [items, H], item_bias = output_layer.bias — sigmoid is monotone, so the
@@ -446,7 +454,7 @@ int yr_mf_eval_topk_bias(const float *U, const float *I, const float *item_bias,
                          int64_t nrows, int D, int64_t num_users, int64_t num_items,
                          const int64_t *mask_ptr, const int64_t *mask_idx, float mask_value,
                          int k, int64_t *out, void *workspace, int64_t workspace_bytes, int mode,
-                         int32_t *err_flag, void *stream);
+                         const int64_t *hint, int32_t *err_flag, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Masked row-wise top-k      (reference trainers/mf_trainer.py:163-178,

@@ -23,6 +23,18 @@ for k in (10, 4, 16):
     for prec in ("f32", "bf16x3"):
         tk(f"k={k} {prec}", lambda: out.__setitem__((k, prec), engine.mf_eval_topk(U, I, users, ptr, sidx, k, precision=prec)))
         tk(f"k={k} {prec} no prescan", lambda: out.__setitem__((k, prec, 0), engine.mf_eval_topk(U, I, users, ptr, sidx, k, precision=prec, prescan=False)))
+own = out[(10, "bf16x3")]
+tk('k=10 bf16x3 hint = own result', lambda: engine.mf_eval_topk(U, I, users, ptr, sidx, 10, hint=own))
+for eps in (0.01, 0.03, 0.1):
+    U2 = U + eps * 0.1 * torch.randn(U.shape, device=dev, generator=g); I2 = I + eps * 0.1 * torch.randn(I.shape, device=dev, generator=g)
+    old = engine.mf_eval_topk(U2, I2, users, ptr, sidx, 10)
+    kept = (old.unsqueeze(2) == own.unsqueeze(1)).any(2).float().mean().item()
+    tk(f'k=10 bf16x3 hint = result of tables perturbed by {eps:g} sigma ({kept:.0%} of the top-10 kept)',
+       lambda: out.__setitem__('h', engine.mf_eval_topk(U, I, users, ptr, sidx, 10, hint=old)))
+    print('   == no hint:', bool((out['h'] == own).all()))
+tk('k=10 f32 hint = own result', lambda: engine.mf_eval_topk(U, I, users, ptr, sidx, 10, precision="f32", hint=out[(10, "f32")]))
+tk('k=16 bf16x3 hint = own result', lambda: engine.mf_eval_topk(U, I, users, ptr, sidx, 16, hint=out[(16, "bf16x3")]))
+tk('k=4 bf16x3 hint = own result', lambda: engine.mf_eval_topk(U, I, users, ptr, sidx, 4, hint=out[(4, "bf16x3")]))
 tk('k=10 bf16x3 no masks', lambda: engine.mf_eval_topk(U, I, users, None, None, 10))
 tk('k=10 bf16x3 unsliced', lambda: engine.mf_eval_topk(U, I, users, ptr, sidx, 10, sliced=False))
 a, b = out[(10, "f32")].cpu().numpy(), out[(10, "bf16x3")].cpu().numpy()

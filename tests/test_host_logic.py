@@ -73,16 +73,16 @@ def test_argument_checks_without_gpu():
     assert lib.yr_adam_dense_flat(None, None, None, None, None, None, None, None, None, None, 0, 1e-3, 1e-3, 1.0, 0.9,
                                   0.999, 1e-8, 0.0, 0, None) == 0
     assert lib.yr_mf_eval_topk_bias(None, None, None, None, 4, 64, 10, 10, None, None, 0.0, 17, None, None, 0, 0, None,
-                                    None) == -2                                                     # k > 16
+                                    None, None) == -2                                               # k > 16
     assert lib.yr_mf_eval_topk_bias(None, None, None, None, 4, 64, 10, 10, None, None, 0.0, 10, None, None, 0, 8, None,
-                                    None) == -2                                                     # unknown mode bit
+                                    None, None) == -2                                               # unknown mode bit
     assert lib.yr_mf_eval_topk_bias(None, None, None, None, 4, 64, 10, 10, None, None, 0.0, 10, None, None, 0, 6, None,
-                                    None) == -2                                                     # prescan off AND forced
+                                    None, None) == -2                                               # prescan off AND forced
     assert lib.yr_mf_eval_topk_planes_bytes(1000, 64) == 1000 * 6 * 64
     assert lib.yr_mf_eval_topk_planes_bytes(1000, 48) == -2
-    assert lib.yr_mf_eval_topk_workspace_bytes(128, 1000, 64, 10, 1) == 1000 * 6 * 64               # one slice: planes only
-    assert lib.yr_mf_eval_topk_workspace_bytes(128, 1000, 64, 10, 0) == 0
-    assert lib.yr_mf_eval_topk_workspace_bytes(128, 1000, 64, 10, 4) == 128 * 128                   # forced prescan: maxima
+    assert lib.yr_mf_eval_topk_workspace_bytes(128, 1000, 64, 10, 1) == 1000 * 6 * 64 + 512         # one slice: planes + row thresholds
+    assert lib.yr_mf_eval_topk_workspace_bytes(128, 1000, 64, 10, 0) == 512
+    assert lib.yr_mf_eval_topk_workspace_bytes(128, 1000, 64, 10, 4) == 512 + 128 * 128             # forced prescan: maxima
     assert lib.yr_mf_eval_topk_workspace_bytes(128, 20000, 64, 10, 0) > lib.yr_mf_eval_topk_workspace_bytes(128, 20000, 64, 10, 2)
     assert lib.yr_mf_eval_topk_workspace_bytes(128, 20000, 64, 4, 0) == lib.yr_mf_eval_topk_workspace_bytes(128, 20000, 64, 4, 2)
 

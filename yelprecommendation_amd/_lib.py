@@ -13,7 +13,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
-ENGINE_VERSION = 26
+ENGINE_VERSION = 27
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -72,8 +72,8 @@ SIGNATURES = {
     "yr_mf_scores_gemm": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _p, _p],
     "yr_mf_eval_topk_planes_bytes": [_i64, _int],
     "yr_mf_eval_topk_workspace_bytes": [_i64, _i64, _int, _int, _int],
-    "yr_mf_eval_topk": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _f, _int, _p, _p, _i64, _int, _p, _p],
-    "yr_mf_eval_topk_bias": [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _f, _int, _p, _p, _i64, _int, _p, _p],
+    "yr_mf_eval_topk": [_p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _f, _int, _p, _p, _i64, _int, _p, _p, _p],
+    "yr_mf_eval_topk_bias": [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _p, _f, _int, _p, _p, _i64, _int, _p, _p, _p],
     "yr_topk_masked": [_p, _i64, _i64, _i64, _p, _p, _p, _f, _int, _p, _p],
     "yr_rank_metrics_workspace_bytes": [_i64],
     "yr_rank_metrics": [_p, _i64, _int, _p, _p, _p, _p, _p, _p],

@@ -146,6 +146,56 @@ __global__ __launch_bounds__(kBlock) void et_split_rows_kernel(const float* __re
   planes[(row * 3 + 2) * D8 + c] = p3;
 }
 
+// A threshold from HINT lists (hint[r, 0..k): any k item ids per row — the top-k of an earlier evaluation of a
+// model that has moved a little since): k DIFFERENT items whose scores are all >= b prove that the row's k-th best
+// score is >= b, wherever the ids came from.  One lane group per row computes the k dot products in plain f32
+// together with A = sum_d |u_d i_d| (+ |bias|), lowers each by 1.6e-5 A — more than this kernel's and the sweep's
+// rounding of the same score can differ by (64 terms: <= 3.8e-6 A each) —, gives masked hints the mask value they
+// have in the sweep, and writes the smallest: row_tau[r].  Out-of-range or repeated ids, or a bad user id: no
+// bound (-inf).  A stale or arbitrary hint costs candidates, never correctness.
+template <int D>
+__global__ __launch_bounds__(kBlock) void et_hint_bound_kernel(
+    const float* __restrict__ U, const float* __restrict__ I, const float* __restrict__ item_bias,
+    const int64_t* __restrict__ users, int64_t nrows, int64_t num_users, int64_t num_items,
+    const int64_t* __restrict__ mask_ptr, const int64_t* __restrict__ mask_idx, float mask_value,
+    const int64_t* __restrict__ hint, int k, float* __restrict__ row_tau) {
+  constexpr int LPR = D / 4;                         // lanes per row: 16 bytes of the row each
+  const int l = threadIdx.x % LPR;
+  const int64_t row = (int64_t)blockIdx.x * (kBlock / LPR) + threadIdx.x / LPR;
+  const int64_t r = row < nrows ? row : nrows - 1;   // every lane group runs the loops (shuffles below)
+  const int64_t uid = users[r];
+  bool valid = (uint64_t)uid < (uint64_t)num_users;
+  const float4 u = valid ? *reinterpret_cast<const float4*>(U + uid * D + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t m_lo = mask_ptr ? mask_ptr[r] : 0, m_hi = mask_ptr ? mask_ptr[r + 1] : 0;
+  float bound = INFINITY;
+  for (int j = 0; j < k; ++j) {
+    const int64_t it = hint[r * k + j];
+    const bool in = (uint64_t)it < (uint64_t)num_items;
+    const float4 v = in ? *reinterpret_cast<const float4*>(I + it * D + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float s = u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+    float a = fabsf(u.x * v.x) + fabsf(u.y * v.y) + fabsf(u.z * v.z) + fabsf(u.w * v.w);
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) {
+      s += __shfl_xor(s, off, LPR);
+      a += __shfl_xor(a, off, LPR);
+    }
+    bool dup = false;
+    for (int jj = 0; jj < j; ++jj) dup |= hint[r * k + jj] == it;
+    int64_t lo = m_lo, hi = m_hi;                    // it among the row's (ascending) masked ids?
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (mask_idx[mid] < it) lo = mid + 1;
+      else hi = mid;
+    }
+    const bool masked = lo < m_hi && mask_idx[lo] == it;
+    const float b = item_bias && in ? item_bias[it] : 0.0f;
+    const float eff = masked ? mask_value : (s + b) - 1.6e-5f * (a + fabsf(b));
+    valid = valid && in && !dup;
+    bound = fminf(bound, eff);
+  }
+  if (row < nrows && l == 0) row_tau[row] = valid && k > 0 ? bound : -INFINITY;
+}
+
 // items per LDS stage: 64 where three workgroups per CU fit with it (f32; SPLIT at D <= 32), else 32 — except SPLIT
 // at D = 64 with 16-entry lists, whose registers allow two workgroups per CU either way
 __host__ __device__ constexpr int et_chunk_items(int D, int KK, bool split) {
@@ -176,7 +226,8 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
     const int64_t* __restrict__ users, int64_t nrows,
     int64_t num_users, int num_items, const int64_t* __restrict__ mask_ptr, const int64_t* __restrict__ mask_idx,
     float mask_value, int k, int64_t* __restrict__ out, TopEntry* __restrict__ partial, int items_per_slice,
-    float* __restrict__ gmax, int parts, int chunk_stride, int32_t* __restrict__ err_flag) {
+    float* __restrict__ gmax, int parts, int chunk_stride, const float* __restrict__ row_tau,
+    int32_t* __restrict__ err_flag) {
   constexpr int HALF = D / 2;
   constexpr int KB = D / 16;                                      // SPLIT: 16-deep matrix instructions per plane pair
   constexpr int CH = et_chunk_items(D, KK, SPLIT);                // items per LDS stage
@@ -235,8 +286,11 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
   int32_t Li[KK];
 #pragma unroll
   for (int e = 0; e < KK; ++e) { Ls[e] = ok ? -INFINITY : INFINITY; Li[e] = 0x7fffffff; }   // +inf: nothing ever enters
-  float tau0 = -INFINITY;                            // the floor of the threshold: from the prescan, if there was one
-  if (!PRESCAN && gmax && ok) {
+  float tau0 = -INFINITY;                            // the floor of the threshold: from hint lists or from the prescan
+  if (!PRESCAN && row_tau && ok) {
+    const float b = row_tau[row];                    // strictly below the bound, as for the prescan's
+    tau0 = b < INFINITY ? b - fmaxf(fabsf(b) * 1.0e-6f, 1.0e-30f) : 3.0e38f;
+  } else if (!PRESCAN && gmax && ok) {
     float T[KK];                                     // the KK largest group maxima of this lane's user, descending
 #pragma unroll
     for (int e = 0; e < KK; ++e) T[e] = -INFINITY;
@@ -550,9 +604,11 @@ static int et_slices(int64_t nrows, int64_t num_items) {
   return (int)(S < 1 ? 1 : S);
 }
 
-// Workspace, in this order: the item planes (YR_EVAL_BF16X3), the group maxima of the prescan, the partial lists
+// Workspace, in this order: the item planes (YR_EVAL_BF16X3), the row thresholds of hint lists, the group maxima
+// of the prescan, the partial lists
 static int64_t et_plane_bytes(int64_t num_items, int D) { return (num_items * 6 * D + 255) / 256 * 256; }
 static int64_t et_gmax_bytes(int64_t nrows, int parts) { return (nrows * parts * 32 * 4 + 255) / 256 * 256; }
+static int64_t et_tau_bytes(int64_t nrows) { return (nrows * 4 + 255) / 256 * 256; }
 
 #ifndef YR_ET_SAMPLE_ITEMS
 #define YR_ET_SAMPLE_ITEMS 4096
@@ -581,7 +637,7 @@ extern "C" int64_t yr_mf_eval_topk_planes_bytes(int64_t num_items, int D) {
 extern "C" int64_t yr_mf_eval_topk_workspace_bytes(int64_t nrows, int64_t num_items, int D, int k, int mode) {
   if (nrows < 0 || num_items <= 0 || k <= 0 || k > kEtMaxK || !et_mode_ok(mode) || !et_dim_ok(D)) return YR_ERR_BADARG;
   const int S = et_slices(nrows, num_items);
-  return ((mode & YR_EVAL_BF16X3) ? et_plane_bytes(num_items, D) : 0) +
+  return ((mode & YR_EVAL_BF16X3) ? et_plane_bytes(num_items, D) : 0) + et_tau_bytes(nrows) +
          (et_prescan_wanted(num_items, k, mode) ? et_gmax_bytes(nrows, S) : 0) +
          (S > 1 ? nrows * S * k * (int64_t)sizeof(TopEntry) : 0);
 }
@@ -602,6 +658,7 @@ struct EtArgs {
   int per;
   float* gmax;          // NULL: no prescan
   int parts;
+  const float* row_tau; // NULL: no hint lists
   int32_t* err_flag;
   unsigned row_blocks, slices;
 };
@@ -610,7 +667,7 @@ template <int DD, int KK, bool BB, bool SS, bool PP>
 void et_launch_one(const EtArgs& a, dim3 grid, int chunk_stride, hipStream_t s) {
   hipLaunchKernelGGL((mf_eval_topk_kernel<DD, KK, BB, SS, PP>), grid, dim3(kEtThreads), 0, s, a.U, a.items, a.item_bias,
                      a.users, a.nrows, a.num_users, a.num_items, a.mask_ptr, a.mask_idx, a.mask_value, a.k, a.out,
-                     a.partial, a.per, a.gmax, a.parts, chunk_stride, a.err_flag);
+                     a.partial, a.per, a.gmax, a.parts, chunk_stride, a.row_tau, a.err_flag);
 }
 
 template <int DD, bool BB, bool SS>
@@ -644,8 +701,8 @@ void et_launch_d(const EtArgs& a, bool split, hipStream_t s) {
 extern "C" int yr_mf_eval_topk_bias(const float* U, const float* I, const float* item_bias, const int64_t* users,
                                     int64_t nrows, int D, int64_t num_users, int64_t num_items,
                                     const int64_t* mask_ptr, const int64_t* mask_idx, float mask_value, int k,
-                                    int64_t* out, void* workspace, int64_t workspace_bytes, int mode, int32_t* err_flag,
-                                    void* stream) {
+                                    int64_t* out, void* workspace, int64_t workspace_bytes, int mode,
+                                    const int64_t* hint, int32_t* err_flag, void* stream) {
   if (nrows < 0 || num_users <= 0 || num_items <= 0 || num_items > 0x7ffffff0 || k <= 0 || k > kEtMaxK ||
       !et_mode_ok(mode) || workspace_bytes < 0)
     return YR_ERR_BADARG;
@@ -670,7 +727,25 @@ extern "C" int yr_mf_eval_topk_bias(const float* U, const float* I, const float*
     workspace_bytes -= pb;
   }
   int S = et_slices(nrows, num_items);
-  if (et_prescan_wanted(num_items, k, mode) && workspace_bytes >= et_gmax_bytes(nrows, S)) {   // no room: no prescan
+  if (hint && workspace_bytes >= et_tau_bytes(nrows)) {                       // no room: the hint is ignored
+    float* tau = reinterpret_cast<float*>(ws);
+    const int lpr = D / 4;
+    const dim3 hgrid((unsigned)((nrows + kBlock / lpr - 1) / (kBlock / lpr)));
+#define YR_ET_HINT(DD)                                                                                              \
+  hipLaunchKernelGGL((et_hint_bound_kernel<DD>), hgrid, dim3(kBlock), 0, s, U, I, item_bias, users, nrows, num_users, \
+                     num_items, mask_ptr, mask_idx, mask_value, hint, k, tau)
+    switch (D) {
+      case 16: YR_ET_HINT(16); break;
+      case 32: YR_ET_HINT(32); break;
+      case 64: YR_ET_HINT(64); break;
+      default: YR_ET_HINT(128); break;
+    }
+#undef YR_ET_HINT
+    a.row_tau = tau;
+    ws += et_tau_bytes(nrows);
+    workspace_bytes -= et_tau_bytes(nrows);
+  }
+  if (!a.row_tau && et_prescan_wanted(num_items, k, mode) && workspace_bytes >= et_gmax_bytes(nrows, S)) {   // no room: no prescan
     a.gmax = reinterpret_cast<float*>(ws);
     a.parts = S;
     ws += et_gmax_bytes(nrows, S);
@@ -710,9 +785,10 @@ extern "C" int yr_mf_eval_topk_bias(const float* U, const float* I, const float*
 extern "C" int yr_mf_eval_topk(const float* U, const float* I, const int64_t* users, int64_t nrows, int D,
                                int64_t num_users, int64_t num_items, const int64_t* mask_ptr,
                                const int64_t* mask_idx, float mask_value, int k, int64_t* out, void* workspace,
-                               int64_t workspace_bytes, int mode, int32_t* err_flag, void* stream) {
+                               int64_t workspace_bytes, int mode, const int64_t* hint, int32_t* err_flag,
+                               void* stream) {
   return yr_mf_eval_topk_bias(U, I, nullptr, users, nrows, D, num_users, num_items, mask_ptr, mask_idx, mask_value, k,
-                              out, workspace, workspace_bytes, mode, err_flag, stream);
+                              out, workspace, workspace_bytes, mode, hint, err_flag, stream);
 }
 
 #ifdef YR_ET_STAMPS

@@ -763,7 +763,7 @@ EVAL_MODES = {"f32": 0, "bf16x3": 1}          # YR_EVAL_F32 / YR_EVAL_BF16X3 (in
 
 
 def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALUE, out=None, sliced=True,
-                 item_bias=None, precision="bf16x3", prescan=None):
+                 item_bias=None, precision="bf16x3", prescan=None, hint=None):
     """Fused full-catalogue scoring + mask + top-k (no score matrix).  ``mask_idx_sorted``: CSR mask
     lists with ascending ids inside each row (see :func:`sort_mask_rows`).  ``sliced=False`` withholds
     the room for the partial lists, i.e. forces the one-slice form of the kernel (tests).  ``item_bias``: scores
@@ -771,7 +771,11 @@ def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALU
     three-term bfloat16 splits of both operands on the bf16 matrix instructions (six partial products, error below
     the f32 rounding of a product) — or "f32", the f32 matrix instruction itself.  ``prescan``: None = the
     library's rule (catalogues of 16,384 items and more), False / True = never / always run the sampling launch that
-    gives the lists their starting thresholds (same result either way; ``sliced=False`` implies False)."""
+    gives the lists their starting thresholds (same result either way; ``sliced=False`` implies False).
+    ``hint``: int64 [n, k] item ids, e.g. the result of the previous evaluation of the same rows (may be ``out``
+    itself): the lists start from the smallest score among a row's k hint items, which the row's k-th best score
+    cannot be below — the result does not depend on it, a good hint saves most candidate insertions and the
+    prescan launch."""
     lib = _lib.load()
     nu, ni, d = _table_dims(U, I)
     n = users.numel()
@@ -783,11 +787,13 @@ def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALU
         mode |= 4                                   # YR_EVAL_FORCE_PRESCAN
     if out is None:
         out = torch.empty((n, k), dtype=torch.int64, device=U.device)
+    if hint is not None and tuple(hint.shape) != (n, k):
+        raise EngineError(f"hint must be [{n}, {k}] item ids, got {tuple(hint.shape)}")
     flag = new_error_flag(U.device)
     if sliced:
         ws_bytes = lib.yr_mf_eval_topk_workspace_bytes(n, ni, d, int(k), mode)
     else:
-        ws_bytes = planes_only
+        ws_bytes = planes_only + (-(-n * 4 // 256) * 256 if hint is not None else 0)
     if ws_bytes < 0:
         check(int(ws_bytes), "yr_mf_eval_topk_workspace_bytes")
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=U.device) if ws_bytes else None
@@ -796,7 +802,8 @@ def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALU
                               _dev(users, torch.int64, "users"), n, d, nu, ni,
                               _opt(mask_ptr, torch.int64, "mask_ptr"), _opt(mask_idx_sorted, torch.int64, "mask_idx"),
                               float(mask_value), int(k), _dev(out, torch.int64, "out"),
-                              ws.data_ptr() if ws is not None else None, ws_bytes, mode, flag.data_ptr(), _stream()),
+                              ws.data_ptr() if ws is not None else None, ws_bytes, mode,
+                              _opt(hint, torch.int64, "hint"), flag.data_ptr(), _stream()),
           "yr_mf_eval_topk")
     raise_on_flag(flag, "mf_eval_topk")
     return out

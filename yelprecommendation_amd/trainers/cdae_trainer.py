@@ -142,9 +142,16 @@ class CDAETrainer(BaseTrainer):
             raise NotImplementedError("list batches must cover every user exactly once (CDAEBatchLoader does)")
         (sp, si), (ap, ai) = item_lists["seen"], item_lists["actual"]
         mask_value = engine.MASK_VALUE if model._output_act == engine.ACT_SIGMOID else 0.0
+        # the previous lists of the same pass (validation / test) are the hint of this one (engine.mf_eval_topk)
+        hints = self.__dict__.setdefault("_eval_hints", {}) if self.cfg.get("eval_hints", True) else None
+        hint = hints.get(with_loss) if hints is not None else None
+        if hint is not None and tuple(hint.shape) != (model.num_users, self.cfg.top_n):
+            hint = None
         top = engine.mf_eval_topk(Z, Wo, torch.arange(model.num_users, device=dev), sp, si, self.cfg.top_n,
                                   mask_value=mask_value, item_bias=bo,
-                                  precision=self.cfg.get("eval_precision", "bf16x3"))
+                                  precision=self.cfg.get("eval_precision", "bf16x3"), hint=hint)
+        if hints is not None:
+            hints[with_loss] = top
         model.check_indices()
         return engine.rank_metrics(top, ap, ai)[4:10]
 

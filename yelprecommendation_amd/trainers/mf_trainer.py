@@ -61,6 +61,7 @@ class MFTrainer(BaseTrainer):
         self.loss = self._loss()
         self._loss_accum = torch.zeros(1, dtype=torch.float64, device=self.device)
         self._eval_cache = {}
+        self._eval_hints = {}                              # eval set -> its last top-n lists (hints of the next evaluation)
         dist = _dist()
         self.world_size = dist.get_world_size() if dist else 1
         self.rank = dist.get_rank() if dist else 0
@@ -272,13 +273,23 @@ class MFTrainer(BaseTrainer):
                                      torch.from_numpy(pos_ptr).to(dev), torch.from_numpy(pos_idx).to(dev))
         return self._eval_cache[key][1:5]
 
-    def recommend(self, users, mask_ptr, mask_idx):
-        """Top-``top_n`` item ids per user, masked items excluded ([n_users, top_n] int64, device)."""
+    def recommend(self, users, mask_ptr, mask_idx, hint_key=None):
+        """Top-``top_n`` item ids per user, masked items excluded ([n_users, top_n] int64, device).
+        ``hint_key``: evaluations under the same key hand their result to the next one as hint lists
+        (engine.mf_eval_topk: the lists start from the smallest score among a user's previous top-n under the
+        CURRENT model — a bound the result cannot depend on; cfg.eval_hints=False turns it off)."""
         U, I = self.model.user_embedding.weight.detach(), self.model.item_embedding.weight.detach()
         if self.cfg.top_n <= 16:                          # fused scores + mask + top-k; masks are pre-sorted
             # cfg.eval_precision: "bf16x3" (default; f32 scores from three-term bf16 splits) or "f32"
-            return engine.mf_eval_topk(U, I, users.contiguous(), mask_ptr, mask_idx, self.cfg.top_n,
-                                       precision=self.cfg.get("eval_precision", "bf16x3"))
+            hinted = hint_key is not None and self.cfg.get("eval_hints", True)
+            hint = self._eval_hints.get(hint_key) if hinted else None
+            if hint is not None and tuple(hint.shape) != (users.numel(), self.cfg.top_n):
+                hint = None
+            top = engine.mf_eval_topk(U, I, users.contiguous(), mask_ptr, mask_idx, self.cfg.top_n,
+                                      precision=self.cfg.get("eval_precision", "bf16x3"), hint=hint)
+            if hinted:
+                self._eval_hints[hint_key] = top
+            return top
         return engine.mf_recommend(U, I, users, mask_ptr, mask_idx, self.cfg.top_n, fused=False)
 
     def evaluate(self, eval_data, mode='valid') -> tuple:
@@ -288,11 +299,11 @@ class MFTrainer(BaseTrainer):
         if self.world_size > 1:
             p, r, m, n = self._evaluate_sharded(eval_data, users, mask_ptr, mask_idx)
         elif self.cfg.get("host_metrics", False):
-            predicted = self.recommend(users, mask_ptr, mask_idx)
+            predicted = self.recommend(users, mask_ptr, mask_idx, hint_key=id(eval_data))
             # the checked definition (Python loops of reference metric.py); ~100x the kernel time
             p, r, m, n = ranking_metrics(actual, predicted.cpu().numpy().tolist(), self.cfg.top_n)
         else:
-            predicted = self.recommend(users, mask_ptr, mask_idx)
+            predicted = self.recommend(users, mask_ptr, mask_idx, hint_key=id(eval_data))
             pos_ptr, pos_idx = self._eval_cache[id(eval_data)][5:7]
             p, r, m, n = engine.rank_metrics(predicted, pos_ptr, pos_idx)[:4].tolist()
         if mode == 'test':
@@ -305,7 +316,8 @@ class MFTrainer(BaseTrainer):
         sums = torch.zeros(6, dtype=torch.float64, device=self.device)
         if users.numel():
             pos_ptr, pos_idx = self._eval_cache[id(eval_data)][5:7]
-            sums = engine.rank_metrics(self.recommend(users, mask_ptr, mask_idx), pos_ptr, pos_idx)[4:10].clone()
+            sums = engine.rank_metrics(self.recommend(users, mask_ptr, mask_idx, hint_key=id(eval_data)), pos_ptr,
+                                       pos_idx)[4:10].clone()
         _dist().all_reduce(sums)
         cnt, ps, rs, ms, ns, total = sums.tolist()
         return (ps / total, rs / cnt, ms / cnt, ns / cnt)
