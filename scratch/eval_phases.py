@@ -16,11 +16,14 @@ U = torch.randn(NU, 64, device=dev) * 0.1
 I = torch.randn(NI, 64, device=dev) * 0.1
 users = torch.arange(NU, device=dev)
 buf = (ctypes.c_ulonglong * 8)()
+hint = None
 for rep in range(3):
     lib.yr_debug_eval_phases(buf, 1)
-    engine.mf_eval_topk(U, I, users, ptr, i.contiguous(), int(os.environ.get("YR_K", "10")),
-                        precision=os.environ.get("YR_PRECISION", "bf16x3"),
-                        prescan={"": None, "0": False, "1": True}[os.environ.get("YR_PRESCAN", "")])
+    top = engine.mf_eval_topk(U, I, users, ptr, i.contiguous(), int(os.environ.get("YR_K", "10")),
+                              precision=os.environ.get("YR_PRECISION", "bf16x3"),
+                              prescan={"": None, "0": False, "1": True}[os.environ.get("YR_PRESCAN", "")], hint=hint)
+    if os.environ.get("YR_HINT"):                  # the own result as the hint of the next repetition
+        hint = top
     torch.cuda.synchronize()
     lib.yr_debug_eval_phases(buf, 0)
 v = list(buf)

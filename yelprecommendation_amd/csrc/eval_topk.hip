@@ -59,6 +59,9 @@ constexpr int kEtMaxK = 16;
 #ifndef YR_ET_TARGET_WGS
 #define YR_ET_TARGET_WGS 768
 #endif
+#ifndef YR_ET_EARLY_OUT
+#define YR_ET_EARLY_OUT 1
+#endif
 #ifndef YR_ET_SPLIT_CHUNK
 #define YR_ET_SPLIT_CHUNK 32
 #endif
@@ -474,8 +477,21 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
       // ---- candidates -> private buffer.  Strict comparison is exact: a lane meets its items in
       // ascending id order, so a later score EQUAL to the threshold loses the tie anyway; it also
       // keeps the -inf of the rows beyond the slice out.
+      // With thresholds from hint lists most tiles hold no candidate in the whole wave: the lane's largest score
+      // against its threshold first (8 v_max3 + one compare instead of 16 compare-and-branch blocks).  With the
+      // looser bounds of the prescan, or none, nearly every tile holds one, and the test would only add to it.
+      bool scan = !PRESCAN;
+#if YR_ET_EARLY_OUT
+      if (!PRESCAN && row_tau) {                     // wave-uniform
+        float mx = acc[0];
 #pragma unroll
-      for (int half = 0; half < (PRESCAN ? 0 : 16 / kEtCheckEvery); ++half) {
+        for (int reg = 1; reg < 16; ++reg) mx = fmaxf(mx, acc[reg]);
+        scan = __ballot(mx > tau) != 0ull;
+      }
+#endif
+      if (scan)
+#pragma unroll
+      for (int half = 0; half < 16 / kEtCheckEvery; ++half) {
 #pragma unroll
         for (int q = 0; q < kEtCheckEvery; ++q) {
           const int reg = half * kEtCheckEvery + q;
