@@ -13,5 +13,9 @@ for k in 10 16; do for ps in 0 1; do
   echo "k=$k prescan=$ps" >> $out/eval_phases.txt
   YR_K=$k YR_PRESCAN=$ps scratch/eval_phases.sh >> $out/eval_phases.txt 2>&1 || exit 1
 done; done
+for k in 10 16; do
+  echo "k=$k hint lists (the own result)" >> $out/eval_phases.txt
+  YR_K=$k YR_HINT=1 scratch/eval_phases.sh >> $out/eval_phases.txt 2>&1 || exit 1
+done
 cp $out/lib.keep yelprecommendation_amd/libyelprec_engine.so; rm $out/lib.keep
 echo collected

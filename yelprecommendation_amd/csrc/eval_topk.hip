@@ -156,47 +156,67 @@ __global__ __launch_bounds__(kBlock) void et_split_rows_kernel(const float* __re
 // rounding of the same score can differ by (64 terms: <= 3.8e-6 A each) —, gives masked hints the mask value they
 // have in the sweep, and writes the smallest: row_tau[r].  Out-of-range or repeated ids, or a bad user id: no
 // bound (-inf).  A stale or arbitrary hint costs candidates, never correctness.
+// Sixteen lanes per row, D / 16 floats of the rows each.  Lane l owns hint l: its binary search in the row's masked
+// ids and its repeated-id test run once (not once per lane), the k dot products are shared work (47 us with every
+// lane doing everything, hint after hint; 56 us with the k searches of a lane interleaved).
 template <int D>
 __global__ __launch_bounds__(kBlock) void et_hint_bound_kernel(
     const float* __restrict__ U, const float* __restrict__ I, const float* __restrict__ item_bias,
     const int64_t* __restrict__ users, int64_t nrows, int64_t num_users, int64_t num_items,
     const int64_t* __restrict__ mask_ptr, const int64_t* __restrict__ mask_idx, float mask_value,
     const int64_t* __restrict__ hint, int k, float* __restrict__ row_tau) {
-  constexpr int LPR = D / 4;                         // lanes per row: 16 bytes of the row each
-  const int l = threadIdx.x % LPR;
-  const int64_t row = (int64_t)blockIdx.x * (kBlock / LPR) + threadIdx.x / LPR;
-  const int64_t r = row < nrows ? row : nrows - 1;   // every lane group runs the loops (shuffles below)
+  constexpr int G = 16, C = D / G;                   // k <= kEtMaxK = G
+  const int l = threadIdx.x % G;
+  const int64_t row = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G;
+  const int64_t r = row < nrows ? row : nrows - 1;   // every lane group runs everything (shuffles below)
   const int64_t uid = users[r];
-  bool valid = (uint64_t)uid < (uint64_t)num_users;
-  const float4 u = valid ? *reinterpret_cast<const float4*>(U + uid * D + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const int64_t m_lo = mask_ptr ? mask_ptr[r] : 0, m_hi = mask_ptr ? mask_ptr[r + 1] : 0;
-  float bound = INFINITY;
-  for (int j = 0; j < k; ++j) {
-    const int64_t it = hint[r * k + j];
-    const bool in = (uint64_t)it < (uint64_t)num_items;
-    const float4 v = in ? *reinterpret_cast<const float4*>(I + it * D + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float s = u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
-    float a = fabsf(u.x * v.x) + fabsf(u.y * v.y) + fabsf(u.z * v.z) + fabsf(u.w * v.w);
+  const bool user_ok = (uint64_t)uid < (uint64_t)num_users;
+  float uu[C];
 #pragma unroll
-    for (int off = LPR / 2; off > 0; off >>= 1) {
-      s += __shfl_xor(s, off, LPR);
-      a += __shfl_xor(a, off, LPR);
-    }
-    bool dup = false;
-    for (int jj = 0; jj < j; ++jj) dup |= hint[r * k + jj] == it;
-    int64_t lo = m_lo, hi = m_hi;                    // it among the row's (ascending) masked ids?
-    while (lo < hi) {
-      const int64_t mid = (lo + hi) >> 1;
-      if (mask_idx[mid] < it) lo = mid + 1;
-      else hi = mid;
-    }
-    const bool masked = lo < m_hi && mask_idx[lo] == it;
-    const float b = item_bias && in ? item_bias[it] : 0.0f;
-    const float eff = masked ? mask_value : (s + b) - 1.6e-5f * (a + fabsf(b));
-    valid = valid && in && !dup;
-    bound = fminf(bound, eff);
+  for (int c = 0; c < C; ++c) uu[c] = user_ok ? U[uid * D + C * l + c] : 0.0f;
+  const int64_t h = l < k ? hint[r * k + l] : -1;
+  const int my = (uint64_t)h < (uint64_t)num_items ? (int)h : -1;      // num_items < 2^31
+  // my hint among the row's (ascending) masked ids?
+  const int64_t m_lo = mask_ptr ? mask_ptr[r] : 0;
+  const int len = mask_ptr ? (int)(mask_ptr[r + 1] - m_lo) : 0;
+  const int64_t* mrow = mask_idx + m_lo;
+  int lo = 0, hi = my >= 0 ? len : 0;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (mrow[mid] < my) lo = mid + 1;
+    else hi = mid;
   }
-  if (row < nrows && l == 0) row_tau[row] = valid && k > 0 ? bound : -INFINITY;
+  const bool masked = my >= 0 && lo < len && mrow[lo] == my;
+  bool fine = l >= k || my >= 0;                     // in range, and not a repetition of an earlier hint
+  float mys = 0.0f, mya = 0.0f;
+  for (int j = 0; j < k; ++j) {
+    const int idj = __shfl(my, j, G);
+    fine = fine && !(j < l && l < k && idj == my);
+    float s = 0.0f, a = 0.0f;
+    if (idj >= 0) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float x = uu[c] * I[(int64_t)idj * D + C * l + c];
+        s += x;
+        a += fabsf(x);
+      }
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+      s += __shfl_xor(s, off, G);
+      a += __shfl_xor(a, off, G);
+    }
+    if (l == j) { mys = s; mya = a; }
+  }
+  const float b = item_bias && my >= 0 ? item_bias[my] : 0.0f;
+  float eff = l < k ? (masked ? mask_value : (mys + b) - 1.6e-5f * (mya + fabsf(b))) : INFINITY;
+  int all_fine = fine;
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) {
+    eff = fminf(eff, __shfl_xor(eff, off, G));
+    all_fine &= __shfl_xor(all_fine, off, G);
+  }
+  if (row < nrows && l == 0) row_tau[row] = user_ok && k > 0 && all_fine ? eff : -INFINITY;
 }
 
 // items per LDS stage: 64 where three workgroups per CU fit with it (f32; SPLIT at D <= 32), else 32 — except SPLIT
@@ -745,8 +765,7 @@ extern "C" int yr_mf_eval_topk_bias(const float* U, const float* I, const float*
   int S = et_slices(nrows, num_items);
   if (hint && workspace_bytes >= et_tau_bytes(nrows)) {                       // no room: the hint is ignored
     float* tau = reinterpret_cast<float*>(ws);
-    const int lpr = D / 4;
-    const dim3 hgrid((unsigned)((nrows + kBlock / lpr - 1) / (kBlock / lpr)));
+    const dim3 hgrid((unsigned)((nrows + kBlock / 16 - 1) / (kBlock / 16)));
 #define YR_ET_HINT(DD)                                                                                              \
   hipLaunchKernelGGL((et_hint_bound_kernel<DD>), hgrid, dim3(kBlock), 0, s, U, I, item_bias, users, nrows, num_users, \
                      num_items, mask_ptr, mask_idx, mask_value, hint, k, tau)
