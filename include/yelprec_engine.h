@@ -405,7 +405,8 @@ int yr_mf_scores_gemm(const float *U, const float *I, const int64_t *users, int6
  *   (reference trainers/mf_trainer.py:134-144 + :163-178 for all eval users at once)
  *   out[r, 0..k) = the k best items of user users[r] by U[users[r]] . I[j], after forcing the
  *   scores of the items in mask_idx[mask_ptr[r] .. mask_ptr[r+1]) to mask_value; score
- *   descending, item id ascending among equal scores.  k <= 16.
+ *   descending, item id ascending among equal scores.  k <= 32 (the lists live in registers: 4, 10, 16 or 32
+ *   entries); k > 16 up to D = 64 only (YR_ERR_UNSUPPORTED beyond: yr_mf_scores_gemm + yr_topk_masked).
  * The mask lists must be sorted ASCENDING inside each row (the kernel walks them with a cursor as
  * it sweeps the catalogue).  mask_ptr may be NULL.
  * mode: how the matrix cores compute the f32 scores —

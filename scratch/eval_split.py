@@ -19,7 +19,7 @@ def tk(name, f, n=10):
     torch.cuda.synchronize(); ms = (time.time() - t) / n * 1e3
     print(name, round(ms, 3), 'ms', round(2 * nu * ni * d / ms / 1e9, 1), 'TFLOP/s algorithmic', flush=True)
 out = {}
-for k in (10, 4, 16):
+for k in (10, 4, 16, 20):
     for prec in ("f32", "bf16x3"):
         tk(f"k={k} {prec}", lambda: out.__setitem__((k, prec), engine.mf_eval_topk(U, I, users, ptr, sidx, k, precision=prec)))
         tk(f"k={k} {prec} no prescan", lambda: out.__setitem__((k, prec, 0), engine.mf_eval_topk(U, I, users, ptr, sidx, k, precision=prec, prescan=False)))
@@ -35,6 +35,11 @@ for eps in (0.01, 0.03, 0.1):
 tk('k=10 f32 hint = own result', lambda: engine.mf_eval_topk(U, I, users, ptr, sidx, 10, precision="f32", hint=out[(10, "f32")]))
 tk('k=16 bf16x3 hint = own result', lambda: engine.mf_eval_topk(U, I, users, ptr, sidx, 16, hint=out[(16, "bf16x3")]))
 tk('k=4 bf16x3 hint = own result', lambda: engine.mf_eval_topk(U, I, users, ptr, sidx, 4, hint=out[(4, "bf16x3")]))
+tk('k=20 bf16x3 hint = own result', lambda: engine.mf_eval_topk(U, I, users, ptr, sidx, 20, hint=out[(20, "bf16x3")]))
+tk('k=20 f32 hint = own result', lambda: engine.mf_eval_topk(U, I, users, ptr, sidx, 20, precision="f32", hint=out[(20, "f32")]))
+tk('k=20 unfused (score GEMM + top-k kernel)', lambda: engine.mf_recommend(U, I, users, ptr, idx, 20, fused=False), 3)
+tk('k=7 bf16x3', lambda: engine.mf_eval_topk(U, I, users, ptr, sidx, 7))
+tk('k=12 bf16x3', lambda: engine.mf_eval_topk(U, I, users, ptr, sidx, 12))
 tk('k=10 bf16x3 no masks', lambda: engine.mf_eval_topk(U, I, users, None, None, 10))
 tk('k=10 bf16x3 unsliced', lambda: engine.mf_eval_topk(U, I, users, ptr, sidx, 10, sliced=False))
 a, b = out[(10, "f32")].cpu().numpy(), out[(10, "bf16x3")].cpu().numpy()
@@ -43,6 +48,6 @@ p, ix = ptr.cpu().numpy(), sidx.cpu().numpy()
 lists = [ix[p[r]:p[r + 1]] for r in range(nu)]
 nd = assert_topk_equal_up_to_near_ties(b, a, U.cpu().numpy(), I.cpu().numpy(), users.cpu().numpy(), lists, rel=2e-6)
 print('differing rows, all near-ties at 2e-6 x sum|u_d i_d|:', nd)
-for k in (10, 4, 16):
+for k in (10, 4, 16, 20):
     for prec in ("f32", "bf16x3"):
         print(f'k={k} {prec}: prescan == no prescan:', bool((out[(k, prec)] == out[(k, prec, 0)]).all()))

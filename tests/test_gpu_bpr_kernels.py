@@ -206,7 +206,8 @@ def test_fused_eval_topk_edge_cases(device, d):
     ptr = np.zeros(n + 1, np.int64); ptr[1:] = np.cumsum([len(l) for l in lists])
     idx = np.concatenate(lists).astype(np.int64)
     t = lambda a: torch.from_numpy(a).to(device)
-    for k in (1, 10, 16):
+    for k in (1, 7, 10, 12, 16) + ((20, 32) if d <= 64 else ()):              # 32-entry lists up to D = 64; 7, 12, 20:
+        # k below the list length (10, 16, 32) — phantom entries keep the threshold at the k-th best
         b = engine.mf_recommend(t(U), t(I), t(users), t(ptr), t(idx), k, fused=False).cpu().numpy()
         for precision in ("bf16x3", "f32"):
             a = engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, precision=precision).cpu().numpy()
@@ -242,7 +243,7 @@ def test_fused_eval_catalogue_slices_equal_one_slice(device, ni, expect_slices, 
     idx = np.concatenate(lists).astype(np.int64)
     t = lambda a: torch.from_numpy(a).to(device)
     lib = _lib.load()
-    for k in (1, 10, 16):
+    for k in (1, 10, 16, 20):
         planes = lib.yr_mf_eval_topk_planes_bytes(ni, d)
         assert planes == -(-ni * 6 * d // 256) * 256
         taus = -(-n * 4 // 256) * 256                                        # row thresholds of hint lists
@@ -402,7 +403,7 @@ def test_fused_eval_hint_lists_never_change_the_result(device, d, precision):
     and with EXACT score ties at the k-th place (duplicated item rows: the tie must still go to the smaller id)."""
     from yelprecommendation_amd import engine
     rs = np.random.RandomState(900 + d)
-    nu, ni, n, k = 90, 5003, 77, 10
+    nu, ni, n, k = 90, 5003, 77, (20 if d == 16 else 10)          # 20: a lane of the hint kernel owns two hints
     U, I = _tables(rs, nu, ni, d)
     I[1000:1500] = I[2000:2500]                                   # 500 pairs of items with identical scores for every user
     bias = (rs.standard_normal(ni) * 0.05).astype(np.float32)
@@ -427,4 +428,4 @@ def test_fused_eval_hint_lists_never_change_the_result(device, d, precision):
         engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, hint=out, out=out, **kw)
         assert torch.equal(out, want)
     with pytest.raises(Exception):
-        engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, hint=want[:, :5].contiguous())
+        engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, hint=want[:, :3].contiguous())

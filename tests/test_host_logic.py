@@ -72,8 +72,10 @@ def test_argument_checks_without_gpu():
                                   0.999, 1e-8, 0.0, 0, None) == -2                                  # > 16 tensors
     assert lib.yr_adam_dense_flat(None, None, None, None, None, None, None, None, None, None, 0, 1e-3, 1e-3, 1.0, 0.9,
                                   0.999, 1e-8, 0.0, 0, None) == 0
-    assert lib.yr_mf_eval_topk_bias(None, None, None, None, 4, 64, 10, 10, None, None, 0.0, 17, None, None, 0, 0, None,
-                                    None, None) == -2                                               # k > 16
+    assert lib.yr_mf_eval_topk_bias(None, None, None, None, 4, 64, 10, 10, None, None, 0.0, 33, None, None, 0, 0, None,
+                                    None, None) == -2                                               # k > 32
+    assert lib.yr_mf_eval_topk_bias(None, None, None, None, 4, 128, 10, 10, None, None, 0.0, 20, None, None, 0, 0, None,
+                                    None, None) == -1                                               # k > 16 at D = 128: unsupported
     assert lib.yr_mf_eval_topk_bias(None, None, None, None, 4, 64, 10, 10, None, None, 0.0, 10, None, None, 0, 8, None,
                                     None, None) == -2                                               # unknown mode bit
     assert lib.yr_mf_eval_topk_bias(None, None, None, None, 4, 64, 10, 10, None, None, 0.0, 10, None, None, 0, 6, None,

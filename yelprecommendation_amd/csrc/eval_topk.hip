@@ -44,7 +44,7 @@ constexpr int kEtWaves = 4;
 constexpr int kEtThreads = kEtWaves * kWave;
 constexpr int kEtUsers = kEtWaves * kEtUsersPerWave;   // 128 per workgroup
 constexpr int kEtChunkItems = 64;                      // items per LDS stage (two 32-item tiles)
-constexpr int kEtMaxK = 16;
+constexpr int kEtMaxK = 32;
 // Candidate buffers of 8 slots (flush when some lane holds more than 4, checked after every 4 accumulator
 // registers) and three catalogue slices at Yelp2018 size leave room for three workgroups per CU (f32 form:
 // 2.08 -> 1.94 ms; 16 slots / check every 8 / two per CU before; 6 to 13 slots make no difference in the split form).
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void et_hint_bound_kernel(
     const int64_t* __restrict__ users, int64_t nrows, int64_t num_users, int64_t num_items,
     const int64_t* __restrict__ mask_ptr, const int64_t* __restrict__ mask_idx, float mask_value,
     const int64_t* __restrict__ hint, int k, float* __restrict__ row_tau) {
-  constexpr int G = 16, C = D / G;                   // k <= kEtMaxK = G
+  constexpr int G = 16, C = D / G, HPL = kEtMaxK / G;  // lane l owns hints l, l + 16, ...
   const int l = threadIdx.x % G;
   const int64_t row = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G;
   const int64_t r = row < nrows ? row : nrows - 1;   // every lane group runs everything (shuffles below)
@@ -174,24 +174,33 @@ __global__ __launch_bounds__(kBlock) void et_hint_bound_kernel(
   float uu[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) uu[c] = user_ok ? U[uid * D + C * l + c] : 0.0f;
-  const int64_t h = l < k ? hint[r * k + l] : -1;
-  const int my = (uint64_t)h < (uint64_t)num_items ? (int)h : -1;      // num_items < 2^31
-  // my hint among the row's (ascending) masked ids?
   const int64_t m_lo = mask_ptr ? mask_ptr[r] : 0;
   const int len = mask_ptr ? (int)(mask_ptr[r + 1] - m_lo) : 0;
   const int64_t* mrow = mask_idx + m_lo;
-  int lo = 0, hi = my >= 0 ? len : 0;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (mrow[mid] < my) lo = mid + 1;
-    else hi = mid;
+  int my[HPL];
+  bool masked[HPL];
+  bool fine = true;                                  // every owned hint in range and not a repetition of an earlier one
+#pragma unroll
+  for (int t = 0; t < HPL; ++t) {
+    const int slot = l + G * t;
+    const int64_t h = slot < k ? hint[r * k + slot] : -1;
+    my[t] = (uint64_t)h < (uint64_t)num_items ? (int)h : -1;          // num_items < 2^31
+    fine = fine && (slot >= k || my[t] >= 0);
+    int lo = 0, hi = my[t] >= 0 ? len : 0;           // my hint among the row's (ascending) masked ids?
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (mrow[mid] < my[t]) lo = mid + 1;
+      else hi = mid;
+    }
+    masked[t] = my[t] >= 0 && lo < len && mrow[lo] == my[t];
   }
-  const bool masked = my >= 0 && lo < len && mrow[lo] == my;
-  bool fine = l >= k || my >= 0;                     // in range, and not a repetition of an earlier hint
-  float mys = 0.0f, mya = 0.0f;
+  float mys[HPL], mya[HPL];
+#pragma unroll
+  for (int t = 0; t < HPL; ++t) mys[t] = mya[t] = 0.0f;
   for (int j = 0; j < k; ++j) {
-    const int idj = __shfl(my, j, G);
-    fine = fine && !(j < l && l < k && idj == my);
+    const int idj = j < G ? __shfl(my[0], j, G) : __shfl(my[HPL - 1], j - G, G);
+#pragma unroll
+    for (int t = 0; t < HPL; ++t) fine = fine && !(j < l + G * t && l + G * t < k && idj == my[t]);
     float s = 0.0f, a = 0.0f;
     if (idj >= 0) {
 #pragma unroll
@@ -206,10 +215,16 @@ __global__ __launch_bounds__(kBlock) void et_hint_bound_kernel(
       s += __shfl_xor(s, off, G);
       a += __shfl_xor(a, off, G);
     }
-    if (l == j) { mys = s; mya = a; }
+#pragma unroll
+    for (int t = 0; t < HPL; ++t)
+      if (l + G * t == j) { mys[t] = s; mya[t] = a; }
   }
-  const float b = item_bias && my >= 0 ? item_bias[my] : 0.0f;
-  float eff = l < k ? (masked ? mask_value : (mys + b) - 1.6e-5f * (mya + fabsf(b))) : INFINITY;
+  float eff = INFINITY;
+#pragma unroll
+  for (int t = 0; t < HPL; ++t) {
+    const float b = item_bias && my[t] >= 0 ? item_bias[my[t]] : 0.0f;
+    if (l + G * t < k) eff = fminf(eff, masked[t] ? mask_value : (mys[t] + b) - 1.6e-5f * (mya[t] + fabsf(b)));
+  }
   int all_fine = fine;
 #pragma unroll
   for (int off = G / 2; off > 0; off >>= 1) {
@@ -308,7 +323,9 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
   float Ls[KK];
   int32_t Li[KK];
 #pragma unroll
-  for (int e = 0; e < KK; ++e) { Ls[e] = ok ? -INFINITY : INFINITY; Li[e] = 0x7fffffff; }   // +inf: nothing ever enters
+  // Only the top k leave the kernel: the first KK - k places are held by phantom entries (+inf, no item), so the
+  // list's last score — the threshold — is the lane's k-th best, not its KK-th.  (+inf everywhere: nothing enters.)
+  for (int e = 0; e < KK; ++e) { Ls[e] = (!ok || e < KK - k) ? INFINITY : -INFINITY; Li[e] = 0x7fffffff; }
   float tau0 = -INFINITY;                            // the floor of the threshold: from hint lists or from the prescan
   if (!PRESCAN && row_tau && ok) {
     const float b = row_tau[row];                    // strictly below the bound, as for the prescan's
@@ -316,7 +333,7 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
   } else if (!PRESCAN && gmax && ok) {
     float T[KK];                                     // the KK largest group maxima of this lane's user, descending
 #pragma unroll
-    for (int e = 0; e < KK; ++e) T[e] = -INFINITY;
+    for (int e = 0; e < KK; ++e) T[e] = e < KK - k ? INFINITY : -INFINITY;   // the k-th largest ends up last (see Ls)
     const float4* g4 = reinterpret_cast<const float4*>(gmax + row * parts * 32);
     for (int q = 0; q < parts * 8; ++q) {
       const float4 g = g4[q];
@@ -583,14 +600,15 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
   if (h == 0 && row < nrows) {
 #pragma unroll
     for (int e = 0; e < KK; ++e) {
-      if (e < k) {
+      const int o = e - (KK - k);                    // behind the phantom entries
+      if (o >= 0) {
         if (partial) {
           TopEntry t;
           t.s = Ls[e];
           t.i = Li[e];
-          partial[(row * gridDim.y + blockIdx.y) * k + e] = t;
+          partial[(row * gridDim.y + blockIdx.y) * k + o] = t;
         } else {
-          out[row * k + e] = Li[e] == 0x7fffffff ? -1 : (int64_t)Li[e];
+          out[row * k + o] = Li[e] == 0x7fffffff ? -1 : (int64_t)Li[e];
         }
       }
     }
@@ -719,7 +737,8 @@ void et_launch(const EtArgs& a, hipStream_t s) {
   const dim3 grid(a.row_blocks, a.slices);
   if (a.k <= 4) et_launch_one<DD, 4, BB, SS, false>(a, grid, 0, s);
   else if (a.k <= 10) et_launch_one<DD, 10, BB, SS, false>(a, grid, 0, s);
-  else et_launch_one<DD, 16, BB, SS, false>(a, grid, 0, s);
+  else if (a.k <= 16) et_launch_one<DD, 16, BB, SS, false>(a, grid, 0, s);
+  else if constexpr (DD <= 64) et_launch_one<DD, 32, BB, SS, false>(a, grid, 0, s);   // (D = 128: refused by the caller)
 }
 
 template <int DD>
@@ -742,7 +761,7 @@ extern "C" int yr_mf_eval_topk_bias(const float* U, const float* I, const float*
   if (nrows < 0 || num_users <= 0 || num_items <= 0 || num_items > 0x7ffffff0 || k <= 0 || k > kEtMaxK ||
       !et_mode_ok(mode) || workspace_bytes < 0)
     return YR_ERR_BADARG;
-  if (!et_dim_ok(D)) return YR_ERR_UNSUPPORTED;
+  if (!et_dim_ok(D) || (k > 16 && D > 64)) return YR_ERR_UNSUPPORTED;        // 32-entry lists: registers up to D = 64
   if (nrows == 0) return 0;
   if (!U || !I || !users || !out || (mask_ptr && !mask_idx)) return YR_ERR_BADARG;
   hipStream_t s = (hipStream_t)stream;

@@ -759,6 +759,11 @@ def sort_mask_rows(mask_ptr, mask_idx):
     return mask_idx[order].contiguous()
 
 
+def fused_eval_supports(k, d):
+    """The fused evaluation kernel keeps top-k lists of 4 / 10 / 16 / 32 entries in registers (32: up to D = 64)."""
+    return k <= 16 or (k <= 32 and d <= 64)
+
+
 EVAL_MODES = {"f32": 0, "bf16x3": 1}          # YR_EVAL_F32 / YR_EVAL_BF16X3 (include/yelprec_engine.h)
 
 
@@ -812,12 +817,12 @@ def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALU
 def mf_recommend(U, I, users, mask_ptr, mask_idx, k, chunk_users=4096, fused=None):
     """Top-k unmasked items for each user id in ``users`` (reference
     trainers/mf_trainer.py:134-144 + :163-178, batched), all on the device.
-    ``fused`` (default when k <= 16): one kernel, scores on the matrix cores with mask + top-k in the
+    ``fused`` (default when k <= 16, or k <= 32 with D <= 64): one kernel, scores on the matrix cores with mask + top-k in the
     epilogue.  Otherwise: score GEMM into a chunked buffer + the row-wise masked top-k kernel."""
     nu_tab, ni, d = _table_dims(U, I)
     n = users.numel()
     if fused is None:
-        fused = k <= 16
+        fused = fused_eval_supports(k, d)
     if fused:
         return mf_eval_topk(U, I, users.contiguous(), mask_ptr, sort_mask_rows(mask_ptr, mask_idx), k)
     out = torch.empty((n, k), dtype=torch.int64, device=U.device)

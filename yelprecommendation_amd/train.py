@@ -117,11 +117,12 @@ def train(cfg, args):
         from .trainers.cdae_trainer import CDAETrainer
         if cfg.get("fast_loader"):
             from .data.cdae_batches import CDAEBatchLoader
+            from .engine import fused_eval_supports as engine_supports_topn
             # batches as lists straight from the per-user CSR (no dense rows or masks) when the fused step and the
             # fused evaluation can take them: NS-BCE, Adam / AdamW, a hidden size the kernels are built for
             as_lists = bool(cfg.get("list_batches", True)) and cfg.negative_sampling and cfg.get("fused_step", True) \
                 and cfg.optimizer.lower() in ("adam", "adamw") and cfg.hidden_size in (16, 32, 64, 128) \
-                and cfg.top_n <= 16 and args.cdae_data.num_items <= 163840
+                and engine_supports_topn(cfg.top_n, cfg.hidden_size) and args.cdae_data.num_items <= 163840
             # the test metrics over list batches are computed for all users at once (CDAETrainer._scored_by_lists), so
             # the rows per evaluation batch do not enter the result: fewer, larger batches (7.1 -> 5.4 ms at Yelp2018 size)
             rows = lambda mode: max(cfg.batch_size, int(cfg.get("eval_batch_size", 4096))) if as_lists and mode == 'test' \

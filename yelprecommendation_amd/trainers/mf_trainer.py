@@ -279,7 +279,7 @@ class MFTrainer(BaseTrainer):
         (engine.mf_eval_topk: the lists start from the smallest score among a user's previous top-n under the
         CURRENT model — a bound the result cannot depend on; cfg.eval_hints=False turns it off)."""
         U, I = self.model.user_embedding.weight.detach(), self.model.item_embedding.weight.detach()
-        if self.cfg.top_n <= 16:                          # fused scores + mask + top-k; masks are pre-sorted
+        if engine.fused_eval_supports(self.cfg.top_n, U.shape[1]):   # fused scores + mask + top-k; masks are pre-sorted
             # cfg.eval_precision: "bf16x3" (default; f32 scores from three-term bf16 splits) or "f32"
             hinted = hint_key is not None and self.cfg.get("eval_hints", True)
             hint = self._eval_hints.get(hint_key) if hinted else None
