@@ -427,5 +427,10 @@ def test_fused_eval_hint_lists_never_change_the_result(device, d, precision):
         out = want.clone()                                                      # hint and out in the same buffer
         engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, hint=out, out=out, **kw)
         assert torch.equal(out, want)
+    # an item row of NaNs: its scores are never candidates; as a hint it must give no bound (not a bound from k - 1 items)
+    In = I.copy(); In[777] = np.nan
+    want = engine.mf_eval_topk(t(U), t(In), t(users), t(ptr), t(idx), k, precision=precision)
+    hint = want.clone(); hint[:, k - 1] = 777
+    assert torch.equal(engine.mf_eval_topk(t(U), t(In), t(users), t(ptr), t(idx), k, precision=precision, hint=hint), want)
     with pytest.raises(Exception):
         engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, hint=want[:, :3].contiguous())

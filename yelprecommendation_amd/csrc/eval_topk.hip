@@ -223,9 +223,13 @@ __global__ __launch_bounds__(kBlock) void et_hint_bound_kernel(
 #pragma unroll
   for (int t = 0; t < HPL; ++t) {
     const float b = item_bias && my[t] >= 0 ? item_bias[my[t]] : 0.0f;
-    if (l + G * t < k) eff = fminf(eff, masked[t] ? mask_value : (mys[t] + b) - 1.6e-5f * (mya[t] + fabsf(b)));
+    if (l + G * t < k) {
+      const float e = masked[t] ? mask_value : (mys[t] + b) - 1.6e-5f * (mya[t] + fabsf(b));
+      fine = fine && e == e;                         // a NaN score proves nothing (fminf would drop it silently)
+      eff = fminf(eff, e);
+    }
   }
-  int all_fine = fine;
+  int all_fine = fine;                               // (taken after the NaN test above)
 #pragma unroll
   for (int off = G / 2; off > 0; off >>= 1) {
     eff = fminf(eff, __shfl_xor(eff, off, G));
