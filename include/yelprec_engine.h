@@ -416,10 +416,12 @@ int yr_mf_scores_gemm(const float *U, const float *I, const int64_t *users, int6
  *                   what is dropped is below 2^-25 |x y|, less than the f32 rounding of the product, so the scores
  *                   differ from YR_EVAL_F32 by what two f32 summation orders differ by, at 3/8 of the matrix-core
  *                   cycles.  The item planes (6 D bytes per item) are rebuilt from I by every call.
- * workspace: yr_mf_eval_topk_workspace_bytes(nrows, num_items, D, k, mode) bytes of device memory (may be 0 in
- *   YR_EVAL_F32): first the item planes of YR_EVAL_BF16X3 (yr_mf_eval_topk_planes_bytes(num_items, D): required in
- *   that mode, YR_ERR_BADARG without), then the per-slice partial lists when the catalogue is cut into slices to
- *   fill the chip; without room for those the kernel runs unsliced (same result, slower).
+ * workspace: yr_mf_eval_topk_workspace_bytes(nrows, num_items, D, k, mode) bytes of device memory, used in this
+ *   order: the item planes of YR_EVAL_BF16X3 (yr_mf_eval_topk_planes_bytes(num_items, D): required in that mode,
+ *   YR_ERR_BADARG without); 4 bytes per row for the thresholds of hint lists; the group maxima of the prescan; the
+ *   per-slice partial lists when the catalogue is cut into slices to fill the chip.  Everything after the planes is
+ *   optional: without room for a part, the hint is ignored / the prescan skipped / the kernel runs unsliced — the
+ *   same result, slower.
  * ------------------------------------------------------------------------- */
 #define YR_EVAL_F32 0
 #define YR_EVAL_BF16X3 1
