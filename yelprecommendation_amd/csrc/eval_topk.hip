@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kBlock) void et_hint_bound_kernel(
 }
 
 // items per LDS stage: 64 where three workgroups per CU fit with it (f32; SPLIT at D <= 32), else 32 — except SPLIT
-// at D = 64 with 16-entry lists, whose registers allow two workgroups per CU either way
+// at D = 64 with 16- or 32-entry lists, whose registers allow two workgroups per CU either way
 __host__ __device__ constexpr int et_chunk_items(int D, int KK, bool split) {
   return !split ? kEtChunkItems : (D <= 32 ? 64 : (D == 64 && KK > 10 ? 64 : YR_ET_SPLIT_CHUNK));
 }
@@ -259,9 +259,10 @@ __host__ __device__ constexpr int et_chunk_items(int D, int KK, bool split) {
 // sample of the stages only (every chunk_stride-th, dealt round-robin to the parts), and per lane the running maximum
 // of each of its 16 accumulator registers — 16 disjoint groups of items, 32 per user and part, no candidates, no
 // lists.  Masked items count with the mask value, as in the sweep.  The sweep's prologue reads the 32 x parts group
-// maxima of its user: their KK-th largest is reached by KK different items, so it is a lower bound of the user's
-// KK-th best score over the whole catalogue, and every list of the user (both half-waves, every slice) starts with
+// maxima of its user: their k-th largest is reached by k different items, so it is a lower bound of the user's
+// k-th best score over the whole catalogue, and every list of the user (both half-waves, every slice) starts with
 // a threshold just below it instead of -inf.  What the lists then never see could not have ended in the top k.
+// (Hint lists — et_hint_bound_kernel, row_tau — give a bound of the same kind from k rescored items instead.)
 template <int D, int KK, bool BIAS, bool SPLIT, bool PRESCAN>
 __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
     const float* __restrict__ U, const void* __restrict__ I_any, const float* __restrict__ item_bias,
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
     const float b = row_tau[row];                    // strictly below the bound, as for the prescan's
     tau0 = b < INFINITY ? b - fmaxf(fabsf(b) * 1.0e-6f, 1.0e-30f) : 3.0e38f;
   } else if (!PRESCAN && gmax && ok) {
-    float T[KK];                                     // the KK largest group maxima of this lane's user, descending
+    float T[KK];                                     // the largest group maxima of this lane's user, descending
 #pragma unroll
     for (int e = 0; e < KK; ++e) T[e] = e < KK - k ? INFINITY : -INFINITY;   // the k-th largest ends up last (see Ls)
     const float4* g4 = reinterpret_cast<const float4*>(gmax + row * parts * 32);
