@@ -153,3 +153,43 @@ def test_cdae_full_size_step_matches_oracle(device, tmp_path):
         for (name, p), r in zip(model2.named_parameters(), ref.params):
             np.testing.assert_allclose(p.detach().cpu().numpy(), r, rtol=1e-3, atol=2e-6, err_msg=f"{decoder} {name}")
         step.check()
+
+
+def test_evaluation_full_size_every_form_gives_the_same_lists(device):
+    """BASELINE configs[1] size (31,668 users x 38,048 items, ~47 masked items per user, top-10): the fused
+    evaluation in every form — f32 matrix instruction / three-term bf16 splits, prescan on / off, hint lists (own
+    result and the result of perturbed tables), catalogue slices on / off — must give the lists of the f32
+    instruction without prescan; rows may differ between the two precisions only at float near-ties (examined one by
+    one against float64 scores).  A sample of 512 users is checked against the oracle's per-user loop as well, and
+    no list may hold a masked item."""
+    from oracle import mf_eval
+    from replay import assert_topk_equal_up_to_near_ties
+    from yelprecommendation_amd import engine
+    g = torch.Generator(device=device).manual_seed(17)
+    U = torch.randn(NU, D, device=device, generator=g) * 0.1
+    I = torch.randn(NI, D, device=device, generator=g) * 0.1
+    users = torch.arange(NU, device=device)
+    cnt = torch.randint(10, 85, (NU,), device=device, generator=g)
+    ptr = torch.zeros(NU + 1, dtype=torch.int64, device=device)
+    ptr[1:] = torch.cumsum(cnt, 0)
+    idx = engine.sort_mask_rows(ptr, torch.randint(0, NI, (int(ptr[-1]),), device=device, generator=g))
+    k = 10
+    base = engine.mf_eval_topk(U, I, users, ptr, idx, k, precision="f32", prescan=False)
+    for prescan in (True, False):
+        assert torch.equal(engine.mf_eval_topk(U, I, users, ptr, idx, k, precision="f32", prescan=prescan), base)
+    split = engine.mf_eval_topk(U, I, users, ptr, idx, k, precision="bf16x3", prescan=False)
+    for kw in (dict(prescan=True), dict(hint=split), dict(hint=base), dict(sliced=False),
+               dict(hint=engine.mf_eval_topk(U * 1.02 + 0.003, I, users, ptr, idx, k))):
+        assert torch.equal(engine.mf_eval_topk(U, I, users, ptr, idx, k, precision="bf16x3", **kw), split), kw
+    Un, In, pn, xn = U.cpu().numpy(), I.cpu().numpy(), ptr.cpu().numpy(), idx.cpu().numpy()
+    lists = [xn[pn[r]:pn[r + 1]] for r in range(NU)]
+    ndiff = assert_topk_equal_up_to_near_ties(split.cpu().numpy(), base.cpu().numpy(), Un, In, np.arange(NU), lists, rel=2e-6)
+    assert ndiff <= NU // 1000                                                 # near-ties are rare
+    rows = np.random.RandomState(3).choice(NU, 512, replace=False)
+    sub_ptr = np.zeros(len(rows) + 1, np.int64)
+    sub_ptr[1:] = np.cumsum([len(lists[r]) for r in rows])
+    want = mf_eval.recommend(Un, In, rows.astype(np.int64), sub_ptr, np.concatenate([lists[r] for r in rows]).astype(np.int64), k)
+    assert_topk_equal_up_to_near_ties(split.cpu().numpy()[rows], want, Un, In, rows, [lists[r] for r in rows])
+    got = split.cpu().numpy()
+    for r in rows:
+        assert not set(got[r].tolist()) & set(lists[r].tolist())
