@@ -623,14 +623,21 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
 // out[r, :] = the k best of the S sorted partial lists of row r (score descending, item ascending
 // among equal scores; empty slots carry item 0x7fffffff and lose every comparison).  One thread per
 // row: S cursors, k rounds.
-constexpr int kEtMaxSlices = 8;
+// up to 24 slices (a user shard of an 8-GPU run has 31 row blocks: 24 x 31 workgroups; 8 slices: 3,958 users with
+// hints 0.28 -> 0.24 ms, 7,917 users 0.33 -> 0.29 ms)
+#ifndef YR_ET_MAX_SLICES
+#define YR_ET_MAX_SLICES 24
+#endif
+constexpr int kEtMaxSlices = YR_ET_MAX_SLICES;
 
 __global__ __launch_bounds__(kBlock) void mf_eval_merge_kernel(const TopEntry* __restrict__ partial, int64_t nrows,
                                                                int S, int k, int64_t* __restrict__ out) {
   const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (r >= nrows) return;
   const TopEntry* P = partial + r * S * k;
-  int cur[kEtMaxSlices] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int cur[kEtMaxSlices];
+#pragma unroll
+  for (int s = 0; s < kEtMaxSlices; ++s) cur[s] = 0;
   for (int e = 0; e < k; ++e) {
     int best = -1;
     float bs = 0.0f;
