@@ -1,0 +1,43 @@
+"""Randomised consistency check of the fused evaluation: for random shapes / k / D / mask densities / mask values / biases,
+every form (precision x prescan x hint kind x sliced) must return the lists of the plain form of the same precision, and
+the two precisions may differ at float near-ties only (checked against float64).  python scratch/eval_fuzz.py [cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np, torch
+from yelprecommendation_amd import engine
+from replay import assert_topk_equal_up_to_near_ties
+dev = torch.device("cuda")
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+for c in range(cases):
+    d = int(rs.choice([16, 32, 64, 128]))
+    k = int(rs.choice([1, 3, 4, 5, 10, 11, 16] + ([17, 20, 32] if d <= 64 else [])))
+    nu = int(rs.randint(5, 700)); n = int(rs.randint(1, 600))
+    ni = int(rs.choice([rs.randint(k + 1, 200), rs.randint(200, 5000), rs.randint(16384, 40000)]))
+    U = (rs.standard_normal((nu, d)) * rs.choice([0.01, 0.1, 3.0])).astype(np.float32)
+    I = (rs.standard_normal((ni, d)) * rs.choice([0.01, 0.1, 3.0])).astype(np.float32)
+    if rs.rand() < 0.3: I[rs.randint(0, ni, ni // 4)] = I[rs.randint(0, ni, ni // 4)]     # exact score ties
+    users = rs.randint(0, nu, n).astype(np.int64)
+    dens = rs.choice([0.0, 0.001, 0.02, 0.5, 0.999])
+    lists = [np.sort(rs.choice(ni, size=min(ni, rs.binomial(ni, dens)), replace=False)) for _ in range(n)]
+    ptr = np.zeros(n + 1, np.int64); ptr[1:] = np.cumsum([len(l) for l in lists]); idx = np.concatenate(lists).astype(np.int64) if ptr[-1] else np.zeros(0, np.int64)
+    bias = t((rs.standard_normal(ni) * 0.1).astype(np.float32)) if rs.rand() < 0.4 else None
+    mv = float(rs.choice([-3.40282e+38, 0.0, -1.0e30]))
+    args = (t(U), t(I), t(users), t(ptr), t(idx), k)
+    res = {}
+    for prec in ("f32", "bf16x3"):
+        kw = dict(mask_value=mv, item_bias=bias, precision=prec)
+        base = engine.mf_eval_topk(*args, prescan=False, **kw)
+        res[prec] = base
+        junk = t(rs.randint(-1, ni + 1, size=(n, k)).astype(np.int64))
+        older = engine.mf_eval_topk(t(U + 0.02 * np.abs(U).mean() * rs.standard_normal(U.shape).astype(np.float32)), *args[1:], **kw)
+        for name, extra in (("prescan", dict(prescan=True)), ("hint own", dict(hint=base)), ("hint older", dict(hint=older)),
+                            ("hint junk", dict(hint=junk)), ("unsliced", dict(sliced=False)), ("unsliced + hint", dict(sliced=False, hint=older))):
+            got = engine.mf_eval_topk(*args, **kw, **extra)
+            assert torch.equal(got, base), (c, prec, name, d, k, nu, n, ni, dens, mv, bias is not None)
+    if bias is None and mv < -1e29:
+        assert_topk_equal_up_to_near_ties(res["bf16x3"].cpu().numpy(), res["f32"].cpu().numpy(), U, I, users, lists, rel=4e-6)
+    print(f"case {c}: D={d} k={k} users={nu} rows={n} items={ni} mask density {dens} mask value {mv:g} bias {bias is not None}: ok", flush=True)
+print("all", cases, "cases agree")

@@ -434,3 +434,15 @@ def test_fused_eval_hint_lists_never_change_the_result(device, d, precision):
     assert torch.equal(engine.mf_eval_topk(t(U), t(In), t(users), t(ptr), t(idx), k, precision=precision, hint=hint), want)
     with pytest.raises(Exception):
         engine.mf_eval_topk(t(U), t(I), t(users), t(ptr), t(idx), k, hint=want[:, :3].contiguous())
+
+
+def test_fused_eval_accepts_an_empty_mask_index(device):
+    """All mask lists empty: the index tensor has no elements (and no address); same as no masks at all."""
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(8)
+    U, I = _tables(rs, 40, 900, 32)
+    users = np.arange(40, dtype=np.int64)
+    t = lambda a: torch.from_numpy(a).to(device)
+    a = engine.mf_eval_topk(t(U), t(I), t(users), t(np.zeros(41, np.int64)), t(np.zeros(0, np.int64)), 10)
+    b = engine.mf_eval_topk(t(U), t(I), t(users), None, None, 10)
+    assert torch.equal(a, b)

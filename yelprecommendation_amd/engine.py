@@ -784,6 +784,8 @@ def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALU
     lib = _lib.load()
     nu, ni, d = _table_dims(U, I)
     n = users.numel()
+    if mask_idx_sorted is not None and mask_idx_sorted.numel() == 0:
+        mask_ptr = mask_idx_sorted = None              # every list empty: an empty tensor has no address to pass
     mode = EVAL_MODES[precision]
     planes_only = lib.yr_mf_eval_topk_planes_bytes(ni, d) if mode else 0
     if prescan is False or not sliced:
