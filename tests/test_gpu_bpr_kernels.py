@@ -446,3 +446,6 @@ def test_fused_eval_accepts_an_empty_mask_index(device):
     a = engine.mf_eval_topk(t(U), t(I), t(users), t(np.zeros(41, np.int64)), t(np.zeros(0, np.int64)), 10)
     b = engine.mf_eval_topk(t(U), t(I), t(users), None, None, 10)
     assert torch.equal(a, b)
+    for fused in (True, False):                                                # the same through mf_recommend / topk_masked
+        c = engine.mf_recommend(t(U), t(I), t(users), t(np.zeros(41, np.int64)), t(np.zeros(0, np.int64)), 10, fused=fused)
+        assert_topk_equal_up_to_near_ties(c.cpu().numpy(), a.cpu().numpy(), U, I, users)

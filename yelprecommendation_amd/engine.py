@@ -721,6 +721,8 @@ def topk_masked(scores, mask_ptr, mask_idx, k, mask_value=MASK_VALUE, out=None, 
         out = torch.empty((R, k), dtype=torch.int64, device=scores.device)
     if mask_ptr is not None and mask_rows is None and mask_ptr.numel() != R + 1:
         raise EngineError("mask_ptr must have rows + 1 entries")
+    if mask_idx is not None and mask_idx.numel() == 0:
+        mask_ptr = mask_idx = mask_rows = None             # every list empty: an empty tensor has no address to pass
     if mask_rows is not None and mask_rows.numel() != R:
         raise EngineError("mask_rows must have one entry per row")
     check(lib.yr_topk_masked(scores.data_ptr(), R, N, scores.stride(0) if R > 1 else N,
