@@ -1,0 +1,61 @@
+"""Randomised check of the fused CDAE step (cdae_step.CDAEStep, both decoders) against the autograd route over three steps
+from the same init with the same dropout seeds: random catalogue widths (ragged), hidden sizes, batch sizes, densities,
+NS-BCE / BCE, transposed W_h on and off, corruption levels, duplicate users, empty rows.  python scratch/cdae_fuzz.py [cases] [seed]"""
+import os, sys, tempfile
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np, torch
+from yelprecommendation_amd import engine
+from yelprecommendation_amd.cdae_step import CDAEStep
+from yelprecommendation_amd.loss import BCELoss, NSBCELoss
+from yelprecommendation_amd.models.cdae import CDAE
+from yelprecommendation_amd.optim import Adam
+from yelprecommendation_amd.utils import make_config
+dev = torch.device("cuda")
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+tmp = tempfile.mkdtemp()
+t = lambda a: torch.from_numpy(a).to(dev)
+for c in range(cases):
+    ni = int(rs.choice([rs.randint(40, 300), rs.randint(300, 3000), rs.randint(3000, 9000)]))
+    H = int(rs.choice([16, 32, 64, 100, 128, 256])); nu = int(rs.randint(2, 400)); B = int(rs.choice([1, 2, 31, 40, 256, 300]))
+    ns = bool(rs.rand() < 0.7); decoder = str(rs.choice(["sampled", "dense"])) if ns and H != 100 else "dense"
+    twh = bool(rs.rand() < 0.5); p = float(rs.choice([0.0, 0.3, 0.6])); dens = float(rs.choice([0.002, 0.02, 0.2]))
+    batches = []
+    for _ in range(3):
+        u = rs.randint(0, nu, B).astype(np.int64)
+        x = (rs.rand(B, ni) < dens).astype(np.float32)
+        if B > 3: x[3] = 0.0
+        neg = ((rs.rand(B, ni) < 0.1) * (1 - x)).astype(np.float32)
+        if ns and float((x + neg).sum()) == 0: neg[0, 0] = 1.0 - x[0, 0]; x[0, 1 % ni] = 1.0
+        batches.append((u, x, neg, int(rs.randint(1, 1 << 40))))
+    out = {}
+    for fused in (False, True):
+        torch.manual_seed(c)
+        model = CDAE(make_config("CDAE", hidden_size=H, device="cuda", model_dir=tmp, lr=1e-3, corruption_level=p), ni, nu)
+        model.train()
+        opt = Adam(model.parameters(), lr=1e-3)
+        losses = []
+        if fused:
+            step = CDAEStep(model, opt, ns, decoder=decoder, transposed_wh=twh)
+            for u, x, neg, seed in batches:
+                step.step(t(u), t(x), t(neg) if ns else None, seed=seed, p=p)
+                losses.append(float(step.last_loss()))
+            step.release(); step.check()
+        else:
+            lossf = NSBCELoss() if ns else BCELoss()
+            for u, x, neg, seed in batches:
+                xin = engine.dropout_seeded(t(x), seed, p) if p > 0 else t(x)
+                pred = model.encode_decode(t(u), xin)
+                loss = lossf(pred, t(x), t(neg)) if ns else lossf(pred, t(x))
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(float(loss.detach()))
+        out[fused] = (losses, [q.detach().clone() for q in model.parameters()],
+                      [opt.state[q]["exp_avg"].clone() for q in model.parameters()],
+                      [opt.state[q]["exp_avg_sq"].clone() for q in model.parameters()])
+    tag = f"case {c}: I={ni} H={H} users={nu} B={B} {'NS-BCE' if ns else 'BCE'} {decoder} W_h^T={twh} p={p} density={dens}"
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=5e-6, err_msg=tag)
+    for k in (1, 2, 3):
+        for a, b in zip(out[True][k], out[False][k]):
+            torch.testing.assert_close(a, b, rtol=3e-4, atol=1e-7 + 3e-5 * float(b.abs().max()), msg=lambda m: tag + " " + m)
+    print(tag + ": ok", flush=True)
+print("all", cases, "cases agree")
