@@ -159,9 +159,9 @@ int yr_adam_dense_dual(float *p0, float *g0, float *m0, float *v0, int64_t n0,
  *   lr..weight_decay, step_size, bc2_sqrt, mode: as for yr_adam_dense;
  *   deterministic: non-zero = bitwise reproducible results (the reference is, under a seed: SURVEY 8c):
  *          the contributions of a row are summed in triplet order (the owner pass re-ranks every row by
- *          triplet id after its LDS sort) and chunks are cut at tile boundaries; costs a few percent.
- *          Exception: a bucket that receives more than one chunk (768 / 1024 records) from a SINGLE
- *          tile of the batch is cut inside that tile's segment, in arrival order;
+ *          triplet id after its LDS sort), chunks are cut at tile boundaries, and a tile segment larger
+ *          than a chunk (a few rows taking most of a batch; tables of a few hundred rows) is taken in windows
+ *          of triplet ids; costs a few percent;
  *   workspace: >= yr_bpr_mf_pull_workspace_bytes(B, num_users, num_items, D) bytes, 16-byte
  *          aligned, contents irrelevant on entry (a size computed for max_batch serves every
  *          B <= max_batch).

@@ -32,11 +32,7 @@ for c in range(cases):
     for name in ("atomic", "det"):
         for a, b, tol in zip(out["pull"], out[name], (2e-5, 2e-5, 2e-6, 1e-8, 2e-6, 1e-8, 1e-3)):
             assert torch.allclose(a.double(), b.double(), rtol=2e-3, atol=tol), (c, name, d, nu, ni, B, opt, wd, float((a - b).abs().max()))
-    # bitwise repeats, except where the header's stated exception applies: a bucket that receives more than one chunk
-    # (1,024 records) from a single 4,096-triplet tile — few buckets (small tables) or a few rows taking most of a batch
-    few_buckets = min(nu, ni) * d // 1024 < 16
-    same = all(torch.equal(a, b) for a, b in zip(out["det"], out["det2"]))
-    assert same or any_skew or few_buckets, (c, "deterministic form repeats", d, nu, ni, B)
-    print(f"case {c}: D={d} users={nu} items={ni} B={B} {opt} wd={wd}: ok"
-          + ("" if same else "  (deterministic form: large-segment exception, differs in the last bits)"), flush=True)
+    for a, b in zip(out["det"], out["det2"]):
+        assert torch.equal(a, b), (c, "deterministic form repeats", d, nu, ni, B)
+    print(f"case {c}: D={d} users={nu} items={ni} B={B} {opt} wd={wd}: ok", flush=True)
 print("all", cases, "cases agree")

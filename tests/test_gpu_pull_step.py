@@ -94,6 +94,34 @@ def test_deterministic_mode_is_bitwise_reproducible(device, shape):
     assert abs(runs[0][6].item() - runs[2][6].item()) <= 1e-5 * abs(runs[2][6].item())
 
 
+@pytest.mark.parametrize("d,nu,ni,B", [(16, 300, 200, 24576), (32, 300, 200, 100000), (64, 300, 200, 24576),
+                                       (16, 2516, 3568, 100000), (128, 90, 70, 9000)])
+def test_deterministic_mode_with_oversize_tile_segments(device, d, nu, ni, B):
+    """Few buckets (tables of a few hundred rows) and a handful of items taking most of the positives: a bucket then
+    receives more than one chunk of records from a single tile of the batch.  The owner pass takes such a segment in
+    windows of triplet ids (not in the arrival order the partition's LDS atomics left): three runs of three steps
+    are bit-identical, and equal the atomic form to summation-order tolerance."""
+    from yelprecommendation_amd.bpr_step import BPRMFStep
+    rs = np.random.RandomState(d + B)
+    U0 = torch.from_numpy((rs.standard_normal((nu, d)) * 0.1).astype(np.float32)).to(device)
+    I0 = torch.from_numpy((rs.standard_normal((ni, d)) * 0.1).astype(np.float32)).to(device)
+    t = lambda a: torch.from_numpy(a.astype(np.int64)).to(device)
+    batches = [(t(rs.randint(0, nu, B)), t(np.minimum((rs.pareto(1.2, B) * 3).astype(np.int64), ni - 1)), t(rs.randint(0, ni, B)))
+               for _ in range(3)]
+    runs = []
+    for kw in (dict(deterministic=True), dict(deterministic=True), dict(deterministic=True), dict(impl="atomic")):
+        st = BPRMFStep(U0.clone(), I0.clone(), lr=1e-2, **kw)
+        for b in batches:
+            st.step(*b)
+        st.check()
+        runs.append([x.clone() for x in (st.U, st.I, st.mU, st.vU, st.mI, st.vI)])
+    for other in runs[1:3]:
+        for a, b in zip(runs[0], other):
+            assert torch.equal(a, b)
+    for a, b, tol in zip(runs[0], runs[3], (2e-5, 2e-5, 2e-6, 1e-8, 2e-6, 1e-8)):
+        torch.testing.assert_close(a, b, rtol=2e-3, atol=tol)
+
+
 def test_pull_step_empty_batch_still_decays_state(device):
     """Dense-Adam semantics: a step with no triplets still moves every row (m/v decay)."""
     from yelprecommendation_amd.bpr_step import BPRMFStep

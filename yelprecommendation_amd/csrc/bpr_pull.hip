@@ -402,6 +402,7 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
   __shared__ float4 s_heavy[kWavesPerBlock][LPR];
   __shared__ float s_red[kWavesPerBlock];
   __shared__ int s_scan[kWavesPerBlock];
+  __shared__ int s_n;                            // DET: records kept by the current window of an oversize segment
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   const int grp = lane / LPR, l = lane % LPR;
   const bool finisher = grp < RPW;                // lane groups that finish a row (all of them unless RPW < GPW)
@@ -450,23 +451,84 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
       const int total = s_pre[nt];
       YR_STAMP(2);
 
-      for (int c0 = 0, cend = 0; c0 < total; c0 = cend) {
+      for (int c0 = 0, cend = 0, sub = 0; c0 < total; c0 = cend) {
         cend = min(total, c0 + CAP);
-        if (DET && cend < total) {
-          // cut the chunk at a tile boundary: which records share a chunk must not depend on the
-          // (arbitrary) order inside a tile's segment; a single segment larger than a chunk is cut as it is
+        // DET: which records share a chunk must not depend on the (arbitrary) order inside a tile's segment.  Chunks
+        // are cut at tile boundaries; a segment larger than a chunk is taken in WINDOWS of triplet ids (a window of
+        // CAP ids holds at most CAP user-side records, one of CAP / 2 ids at most CAP item occurrences): every window
+        // scans the whole segment and keeps what falls into it — a fixed set, ranked by triplet id below.
+        int wt = 0;
+        bool windowed = false;
+        if (DET) {
           int tlo = 0, thi = nt;
-          while (thi - tlo > 1) {
+          while (thi - tlo > 1) {                    // the tile whose segment starts at c0 (chunks start at boundaries)
             const int mid = (tlo + thi) >> 1;
-            if (s_pre[mid] <= cend) tlo = mid; else thi = mid;
+            if (s_pre[mid] <= c0) tlo = mid; else thi = mid;
           }
-          if (s_pre[tlo] > c0) cend = s_pre[tlo];
+          wt = tlo;
+          windowed = s_pre[wt + 1] - s_pre[wt] > CAP;
+          if (!windowed && cend < total) {
+            tlo = 0, thi = nt;
+            while (thi - tlo > 1) {
+              const int mid = (tlo + thi) >> 1;
+              if (s_pre[mid] <= cend) tlo = mid; else thi = mid;
+            }
+            if (s_pre[tlo] > c0) cend = s_pre[tlo];
+          }
         }
         if (tid < kWave) s_cnt[tid] = 0;
+        if (DET && tid == 0) s_n = 0;
         __syncthreads();
         // load this chunk's records (flattened index -> tile by binary search) into LDS in load
         // order and rank them by local row; key = local row | rank << 8
         int key[PT];
+        int n_rec = cend - c0;
+        if (DET && windowed) {
+          constexpr int W = USER ? CAP : CAP / 2;
+          const int tile_ids = USER ? a.tile_stride : a.tile_stride >> 1;
+          const int seg = s_pre[wt + 1] - s_pre[wt];
+          const uint32_t rbase = (uint32_t)s_base[wt];
+          const uint32_t id_lo = (uint32_t)(tg0 + wt) * (uint32_t)tile_ids + (uint32_t)sub * (uint32_t)W;
+          for (int sidx = tid; sidx < seg; sidx += kBlock) {
+            if (USER) {
+              const int4 r = static_cast<const int4*>(a.recs)[rbase + sidx];
+              if ((uint32_t)r.z - id_lo < (uint32_t)W) {
+                const int slot = atomicAdd(&s_n, 1);
+                s_x[slot] = r.x; s_y[slot] = r.y; s_z[slot] = r.z;
+                s_idx[slot] = (unsigned short)r.w;     // the local row, until the keys below are taken
+              }
+            } else {
+              const int2 oc = static_cast<const int2*>(a.recs)[rbase + sidx];
+              const uint32_t b = (uint32_t)(oc.y & 0x7fffffff);
+              if (b - id_lo < (uint32_t)W) {
+                const float g = a.coeff[b];
+                const int slot = atomicAdd(&s_n, 1);
+                s_x[slot] = oc.x & kOccMask;
+                s_y[slot] = __float_as_int(oc.y < 0 ? -g : g);
+                s_z[slot] = oc.y;
+                s_idx[slot] = (unsigned short)((uint32_t)oc.x >> kOccShift);
+              }
+            }
+          }
+          __syncthreads();
+          n_rec = s_n;
+#pragma unroll
+          for (int q = 0; q < PT; ++q) {
+            const int c = tid + q * kBlock;
+            key[q] = -1;
+            if (c < n_rec) {
+              const int local = s_idx[c];
+              key[q] = local | (atomicAdd(&s_cnt[local], 1) << 8);
+            }
+          }
+          ++sub;                                       // the next window of this segment, or the next tile boundary
+          if (sub * W >= tile_ids) { sub = 0; cend = s_pre[wt + 1]; }
+          else cend = c0;
+          if (n_rec == 0) {                            // workgroup-uniform: nothing in this window
+            __syncthreads();
+            continue;
+          }
+        } else {
         uint32_t addr[PT];
 #pragma unroll
         for (int q = 0; q < PT; ++q) {
@@ -513,6 +575,7 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
               key[q] = local | (atomicAdd(&s_cnt[local], 1) << 8);
             }
         }
+        }
         __syncthreads();
         // sorted stream = light rows in row order, then the heavy rows (more than heavy_t records)
         if (wave == 0) {
@@ -541,7 +604,7 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
           for (int q = 0; q < PT; ++q) {
             const int pos = tid + q * kBlock;
             at[q] = -1;
-            if (pos < cend - c0) {
+            if (pos < n_rec) {
               ent[q] = s_idx[pos];
               const int r = ent[q] >> kTagShift;
               const uint32_t mine = (uint32_t)s_z[ent[q] & ((1 << kTagShift) - 1)];
@@ -565,7 +628,7 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
                                       GPW, wave * RPW, grp, l, sums, cur, loss);
         }
         // heavy rows of the chunk: all waves on one row, partial sums combined in wave order
-        if ((cend - c0) - s_light[kWave] > 0) {   // workgroup-uniform
+        if (n_rec - s_light[kWave] > 0) {   // workgroup-uniform
 #pragma unroll 1
           for (int r = 0; r < R; ++r) {
             const int cnt = s_cnt[r];
