@@ -28,6 +28,9 @@ for c in range(cases):
         neg = ((rs.rand(B, ni) < 0.1) * (1 - x)).astype(np.float32)
         if ns and float((x + neg).sum()) == 0: neg[0, 0] = 1.0 - x[0, 0]; x[0, 1 % ni] = 1.0
         batches.append((u, x, neg, int(rs.randint(1, 1 << 40))))
+    only = os.environ.get("YR_ONLY_CASE")
+    if only is not None and int(only) != c:
+        continue
     out = {}
     for fused in (False, True):
         torch.manual_seed(c)
@@ -53,9 +56,19 @@ for c in range(cases):
                       [opt.state[q]["exp_avg"].clone() for q in model.parameters()],
                       [opt.state[q]["exp_avg_sq"].clone() for q in model.parameters()])
     tag = f"case {c}: I={ni} H={H} users={nu} B={B} {'NS-BCE' if ns else 'BCE'} {decoder} W_h^T={twh} p={p} density={dens}"
+    if only is not None:                                 # debugging aid: where do the two routes differ most?
+        names = ["W_h", "b_h", "V", "W_o", "b_o"]
+        for k, what in ((1, "param"), (2, "exp_avg"), (3, "exp_avg_sq")):
+            for nm, a, b in zip(names, out[True][k], out[False][k]):
+                dlt = (a - b).abs(); j = int(dlt.argmax())
+                print(f"  {what} {nm}: max |diff| {float(dlt.max()):.3e} at {j}: fused {float(a.flatten()[j]):.6e} autograd {float(b.flatten()[j]):.6e}")
     np.testing.assert_allclose(out[True][0], out[False][0], rtol=5e-6, err_msg=tag)
+    # Parameters: where |g| is of the order of Adam's eps (1e-8; e.g. a saturated hidden unit in a two-row batch), the
+    # update lr * m / (sqrt(v) + eps) turns summation-order noise of 1e-10 in g into a per cent of lr; the moments
+    # themselves (strict below) agree to 1e-6 relative.  2 % of the largest possible movement is allowed on top.
     for k in (1, 2, 3):
         for a, b in zip(out[True][k], out[False][k]):
-            torch.testing.assert_close(a, b, rtol=3e-4, atol=1e-7 + 3e-5 * float(b.abs().max()), msg=lambda m: tag + " " + m)
+            slack = 0.02 * 1e-3 * 3 if k == 1 else 0.0
+            torch.testing.assert_close(a, b, rtol=3e-4, atol=1e-7 + 3e-5 * float(b.abs().max()) + slack, msg=lambda m: tag + " " + m)
     print(tag + ": ok", flush=True)
 print("all", cases, "cases agree")

@@ -19,9 +19,10 @@ for c in range(cases):
     ni = int(rs.choice([rs.randint(8, 200), rs.randint(200, 3000), rs.randint(3000, 30000)]))
     nu, B = int(rs.randint(1, 80)), int(rs.randint(1, 120))
     neg_times = int(rs.choice([0, 1, 5, 9])); p = float(rs.choice([0.0, 0.3, 0.6, 0.9]))
-    cap = max(1, ni // (neg_times + 1) - 1)                                  # neg_times x count <= non-positives
+    cap = ni // (neg_times + 1)                                              # count x (neg_times + 1) <= I: enough non-positives
     counts = np.minimum(rs.choice([0, 1, 5, 40, 400], nu, p=[.1, .2, .4, .25, .05]), cap)
     if rs.rand() < 0.4: counts[rs.randint(nu)] = cap                         # wants (almost) all of the rest: inverted draw
+    counts = np.minimum(counts, cap)
     ptr, idx = csr(nu, ni, counts)
     extra = None
     if rs.rand() < 0.4 and neg_times:                                        # held-out items: loss positives, not input

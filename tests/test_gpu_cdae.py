@@ -708,3 +708,13 @@ def test_train_entry_point_with_device_side_batches(device, tmp_path, list_batch
                           f"list_batches={'true' if list_batches else 'false'}"])
     assert len(metrics) == 4 and all(np.isfinite(m) and 0.0 <= m <= 1.0 for m in metrics)
     assert os.path.exists(os.path.join(str(tmp_path), "best_model.pt"))
+
+
+def test_train_lists_with_an_empty_item_index(device):
+    """No user has an item: the CSR's index tensor is empty (no address); every list comes out empty."""
+    from yelprecommendation_amd import engine
+    t = lambda a: torch.from_numpy(a).to(device)
+    L = engine.TrainLists(t(np.zeros(6, np.int64)), t(np.zeros(0, np.int64)), t(np.arange(5, dtype=np.int64)), 5, 300, 5, 1, 2, 0.5)
+    assert float(L.rows.to_dense().abs().sum()) == 0.0
+    target, neg = L.loss_dense()
+    assert float(target.sum()) == 0.0 and float(neg.sum()) == 0.0

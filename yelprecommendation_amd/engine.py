@@ -415,9 +415,10 @@ class TrainLists:
                    mk(n, torch.int32), mk(n, torch.float32), mk(parts, torch.int32))
             TrainLists._pool = {key: buf}
         i64 = torch.int64
-        check(lib.yr_cdae_train_lists(_dev(ptr, i64, "ptr"), _dev(idx, i64, "idx"),
+        some = lambda t: t if t.numel() else torch.zeros(1, dtype=i64, device=dev)   # an empty index: never read, needs an address
+        check(lib.yr_cdae_train_lists(_dev(ptr, i64, "ptr"), _dev(some(idx), i64, "idx"),
                                       None if extra is None else _dev(extra[0], i64, "ptr2"),
-                                      None if extra is None else _dev(extra[1], i64, "idx2"), _dev(users, i64, "users"), B,
+                                      None if extra is None else _dev(some(extra[1]), i64, "idx2"), _dev(users, i64, "users"), B,
                                       int(num_users), I, int(neg_times), int(neg_seed) & (2**64 - 1),
                                       int(drop_seed) & (2**64 - 1), float(p), *(t.data_ptr() for t in buf),
                                       _opt(err_flag, torch.int32, "err_flag"), _stream()), "yr_cdae_train_lists")
