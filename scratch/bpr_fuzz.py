@@ -29,8 +29,10 @@ for c in range(cases):
         for b in batches: s.step(*b)
         s.check()
         out[name] = [t.clone() for t in (s.U, s.I, s.mU, s.vU, s.mI, s.vI)] + [s.loss_accum.clone().float().reshape(-1)[:1]]
+    # tables: where |g| cancels to the order of Adam's eps, lr * m / (sqrt(v) + eps) turns summation-order noise into a
+    # fraction of lr (here 1e-2 per step): 1 % of the largest possible movement is allowed on top; the moments are strict
     for name in ("atomic", "det"):
-        for a, b, tol in zip(out["pull"], out[name], (2e-5, 2e-5, 2e-6, 1e-8, 2e-6, 1e-8, 1e-3)):
+        for a, b, tol in zip(out["pull"], out[name], (2e-5 + 3e-4, 2e-5 + 3e-4, 2e-6, 1e-8, 2e-6, 1e-8, 1e-3)):
             assert torch.allclose(a.double(), b.double(), rtol=2e-3, atol=tol), (c, name, d, nu, ni, B, opt, wd, float((a - b).abs().max()))
     for a, b in zip(out["det"], out["det2"]):
         assert torch.equal(a, b), (c, "deterministic form repeats", d, nu, ni, B)
