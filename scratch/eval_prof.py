@@ -10,5 +10,10 @@ cnt=torch.randint(10,60,(nu,),device=dev,generator=g)
 ptr=torch.zeros(nu+1,dtype=torch.int64,device=dev); ptr[1:]=torch.cumsum(cnt,0)
 idx=torch.randint(0,ni,(int(ptr[-1]),),device=dev,generator=g)
 sidx=engine.sort_mask_rows(ptr,idx)
-for _ in range(3): engine.mf_eval_topk(U,I,users,ptr,sidx,10)
+# argv[1]: "f32" / "bf16x3" (default); argv[2]: "hint" = every call after the first takes the previous lists as hints
+prec = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
+hinted = len(sys.argv) > 2 and sys.argv[2] == "hint"
+top = None
+for _ in range(4):
+    top = engine.mf_eval_topk(U,I,users,ptr,sidx,10,precision=prec,hint=top if hinted else None)
 torch.cuda.synchronize()
