@@ -280,7 +280,11 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
   constexpr int ROW16 = SPLIT ? 3 * D / 8 : D / 4;                // 16-byte units of payload per item
   constexpr int NV = (CH * ROW16 + kEtThreads - 1) / kEtThreads;  // 16-byte units per thread per chunk
   __shared__ __attribute__((aligned(16))) unsigned char s_items[2][CH * ROWB];   // double-buffered
-  __shared__ TopEntry s_buf[kEtBufCap][kEtThreads];               // slot-major: conflict-free per slot
+  // the split form with 32-item stages has LDS to spare under three workgroups per CU: 12 slots, the fill checked
+  // twice per tile instead of four times (1.10 -> 1.05 ms cold, 0.85 -> 0.83 ms with hints)
+  constexpr int CE = (SPLIT && CH == 32) ? 2 * kEtCheckEvery : kEtCheckEvery;
+  constexpr int BUFCAP = kEtFlushAt + CE;
+  __shared__ TopEntry s_buf[BUFCAP][kEtThreads];                  // slot-major: conflict-free per slot
   __shared__ __attribute__((aligned(16))) float s_bias[2][BIAS ? CH : 4];
   const uint4* __restrict__ I16 = static_cast<const uint4*>(I_any);   // f32 rows or plane rows, 16 bytes at a time
 
@@ -533,10 +537,10 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
 #endif
       if (scan)
 #pragma unroll
-      for (int half = 0; half < 16 / kEtCheckEvery; ++half) {
+      for (int half = 0; half < 16 / CE; ++half) {
 #pragma unroll
-        for (int q = 0; q < kEtCheckEvery; ++q) {
-          const int reg = half * kEtCheckEvery + q;
+        for (int q = 0; q < CE; ++q) {
+          const int reg = half * CE + q;
           float sc = acc[reg];
 #ifdef YR_ET_EXP_NOSCAN      // timing experiment only (wrong results): nothing ever becomes a candidate
           if (sc == 12345.678f) {
