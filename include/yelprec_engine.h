@@ -112,8 +112,9 @@ int yr_bpr_mf_fwd_bwd(const float *U, const float *I,
  * trainers/base_trainer.py:34-38) and reduces the loss partials into loss_out / loss_accum
  * (mf_trainer.py:114 without the host sync).  gradU / gradI: dense, zero on entry and on exit.
  * yr_adam_dense_dual on its own: p0/p1 any two tensors with n0/n1 elements (multiples of 4),
- * touched0/touched1 per row of `row_width` elements or NULL (gradient always read and cleared),
- * loss_partials NULL = no loss reduction.
+ * touched0/touched1 per row of `row_width` elements or NULL (gradient always read and cleared);
+ * with marks, row_width / 4 must divide 64 (the lanes of a row share one wave: 4, 8, 16, 32, 64, 128,
+ * 256 — anything else is YR_ERR_BADARG); loss_partials NULL = no loss reduction.
  * ------------------------------------------------------------------------- */
 int yr_bpr_mf_scatter_step(float *U, float *I, float *gradU, float *gradI,
                            float *mU, float *vU, float *mI, float *vI, uint8_t *touched,

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT/yelprecommendation_amd/csrc" || exit 1
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form -DYR_ET_STAMPS $EXTRA -c eval_topk.hip -o eval_topk.o || exit 1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libyelprec_engine.so *.o || exit 1
-cd ../.. && python3 scratch/eval_phases.py
+# phase cycles of the evaluation sweep (-DYR_ET_STAMPS) on an instrumented COPY of the library (scratch/inst_build.sh)
+lib=$("$(dirname "$0")/inst_build.sh" eval_topk.hip -DYR_ET_STAMPS $EXTRA) || exit 1
+export YR_ENGINE_LIB="$lib"
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" && python3 scratch/eval_phases.py

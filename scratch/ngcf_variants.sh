@@ -3,8 +3,8 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT/yelprecommendation_amd/csrc" || exit 1
 for v in "$@"; do
   echo "=== $v"
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off $v -c ngcf.hip -o ngcf.o || exit 1
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libyelprec_engine.so *.o || exit 1
+  lib=$("$GRAFT_REPO_ROOT/scratch/inst_build.sh" ngcf.hip $v) || exit 1
+  export YR_ENGINE_LIB="$lib"
   (cd ../.. && rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ngcfv -- python3 bench.py --workload ngcf --steps 20 --warmup 5 2>/dev/null | python3 -c "import sys,json; print(json.loads(sys.stdin.read().strip().splitlines()[-1])['value'], 'ms per step')"
    python3 - <<PY
 import csv,glob,os

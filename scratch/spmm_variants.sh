@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT/yelprecommendation_amd/csrc" || exit 1
 for v in "$@"; do
   echo "=== $v"
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off $v -c ngcf.hip -o ngcf.o || exit 1
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libyelprec_engine.so *.o || exit 1
+  lib=$("$GRAFT_REPO_ROOT/scratch/inst_build.sh" ngcf.hip $v) || exit 1
+  export YR_ENGINE_LIB="$lib"
   (cd ../.. && python3 scratch/spmm_time.py) || exit 1
 done

@@ -8,7 +8,6 @@ for w in eval ngcf cdae; do python3 bench.py --workload $w >> $out/bench_other_w
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_eval -- python3 bench.py --workload eval > $out/prof_eval.log 2>&1 || exit 1
 python3 scratch/eval_split.py > $out/eval_split.txt 2>&1 || exit 1
 python3 scratch/cdae_valid_epoch.py 256 lists > $out/cdae_valid_lists.txt 2>&1 || exit 1
-cp yelprecommendation_amd/libyelprec_engine.so $out/lib.keep
 for k in 10 16; do for ps in 0 1; do
   echo "k=$k prescan=$ps" >> $out/eval_phases.txt
   YR_K=$k YR_PRESCAN=$ps scratch/eval_phases.sh >> $out/eval_phases.txt 2>&1 || exit 1
@@ -17,5 +16,4 @@ for k in 10 16; do
   echo "k=$k hint lists (the own result)" >> $out/eval_phases.txt
   YR_K=$k YR_HINT=1 scratch/eval_phases.sh >> $out/eval_phases.txt 2>&1 || exit 1
 done
-cp $out/lib.keep yelprecommendation_amd/libyelprec_engine.so; rm $out/lib.keep
 echo collected

@@ -21,7 +21,8 @@ model is produced here by the same op sequence on CPU (function
 construction, not by execution; everything downstream of it (NGCF forward,
 backward, Adam) is the reference's own code.
 
-Usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
+Usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz, ~1 min)
+        python tests/golden/make_golden.py mf_full    (the headline-size MF run, ~20 min -> mf_full.npz)
 """
 from __future__ import annotations
 
@@ -269,6 +270,157 @@ def golden_mf(out_path, num_users=1000, num_items=1000, mean_items=30.0, embed=3
     )
     print(f"[mf] U={pipe.num_users} I={pipe.num_items} train={len(train_data)} valid={len(valid_data)} "
           f"epochs={len(n_train_steps)} valid_metrics[-1]={epoch_log['valid_metrics'][-1]} test={test_metrics}")
+
+
+# --------------------------------------------------------------------------- #
+# (i')  BPR-MF at the HEADLINE configuration (BASELINE.json configs[1]): the Yelp2018-shaped
+#       synthetic set (31,668 users x 38,048 items, D = 64), the reference's own split, DataLoader,
+#       MFTrainer.run / load_best_model / evaluate on CPU.  ~20 min in the build container.
+#       The fixture is SMALL: hashes of the split and of every epoch's triplet stream (the test
+#       regenerates both with the repo's host mirrors and must hit the same hashes), per-step and
+#       per-epoch losses, the four metrics per epoch and on test, and — for a fixed sample of
+#       users / items — final table rows, Adam moments and the reference's own top-10 lists
+#       (test lists for ALL users: the per-user loop of mf_trainer.py:134-161 is recorded as it runs).
+# --------------------------------------------------------------------------- #
+def _sha(*arrays):
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(np.asarray(a, dtype=np.int64)).tobytes())
+    return h.hexdigest()
+
+
+FULL_FRAME = dict(num_users=31_668, num_items=38_048, mean_items=48.0, seed=1234, min_item_degree=5)
+
+
+def golden_mf_full(out_path, embed=64, lr=5e-3, batch=4096, epochs=2, seed=42, n_sample=512):
+    import time
+    t0 = time.time()
+    cfg = DictConfig(seed=seed, shuffle=True, model_dir=tempfile.mkdtemp(), device="cpu",
+                     epochs=epochs, batch_size=batch, lr=lr, optimizer="adam", loss_name="bpr",
+                     patience=5, top_n=10, weight_decay=0, best_metric="loss", wandb=False,
+                     model_name="MF", embed_size=embed, data_dir="unused")
+    df = make_frame(**FULL_FRAME)
+    print(f"[mf_full] frame {len(df)} rows ({time.time() - t0:.0f} s)", flush=True)
+    pipe = MFDataPipeline(cfg)
+    pipe._set_num_items_and_num_users(df)
+    train_data, valid_data, valid_eval, test_eval = pipe.split(df)   # train.py:161 (the reference's sklearn split)
+    print(f"[mf_full] split: train {len(train_data)} valid {len(valid_data)} ({time.time() - t0:.0f} s)", flush=True)
+    train_ds = MFDataset(train_data, num_items=pipe.num_items)
+    valid_ds = MFDataset(valid_data, num_items=pipe.num_items)
+
+    ref_utils.set_seed(cfg.seed)
+    keys = ("user_id", "pos_item", "neg_item")
+    train_dl = RecordingLoader(DataLoader(train_ds, batch_size=cfg.batch_size, shuffle=cfg.shuffle), keys)
+    valid_dl = RecordingLoader(DataLoader(valid_ds, batch_size=cfg.batch_size, shuffle=cfg.shuffle), keys)
+    trainer = MFTrainer(cfg, pipe.num_items, pipe.num_users)
+    rs = np.random.RandomState(7)
+    su = np.sort(rs.choice(pipe.num_users, n_sample, replace=False)).astype(np.int64)
+    si = np.sort(rs.choice(pipe.num_items, n_sample, replace=False)).astype(np.int64)
+    pU, pI = trainer.model.user_embedding.weight, trainer.model.item_embedding.weight
+    U0s, I0s = pU.detach().numpy()[su].copy(), pI.detach().numpy()[si].copy()
+    init_sum = np.array([pU.detach().double().sum().item(), pI.detach().double().sum().item()])
+    trainer.loss = RecordingLoss(trainer.loss)
+
+    log = {"train": [], "valid": [], "metrics": [], "Us": [], "Is": []}
+    tops = {}                                                        # mode -> list of [k] arrays, call order = frame order
+    o_train, o_valid, o_eval, o_top = trainer.train, trainer.validate, trainer.evaluate, trainer._generate_top_k_recommendation
+    cur = {"mode": None}
+
+    def rec_top(pred, mask_items):
+        out = o_top(pred, mask_items)
+        tops[cur["mode"]].append(np.asarray(out, dtype=np.int64).copy())
+        return out
+
+    def rec_train(dl):
+        v = o_train(dl)
+        log["train"].append(v)
+        log["Us"].append(pU.detach().numpy()[su].copy())
+        log["Is"].append(pI.detach().numpy()[si].copy())
+        print(f"[mf_full] epoch {len(log['train']) - 1} train loss {v:.6f} ({time.time() - t0:.0f} s)", flush=True)
+        return v
+
+    def rec_valid(dl):
+        v = o_valid(dl)
+        log["valid"].append(v)
+        return v
+
+    def rec_eval(data, mode="valid"):
+        key = f"valid{len(log['metrics'])}" if mode == "valid" else "test"
+        cur["mode"] = key
+        tops[key] = []
+        m = o_eval(data, mode)
+        if mode == "valid":
+            log["metrics"].append(m)
+        print(f"[mf_full] evaluate({mode}) = {m} ({time.time() - t0:.0f} s)", flush=True)
+        return m
+
+    trainer.train, trainer.validate, trainer.evaluate = rec_train, rec_valid, rec_eval
+    trainer._generate_top_k_recommendation = rec_top
+    trainer.run(train_dl, valid_dl, valid_eval)                      # train.py:89
+    trainer.load_best_model()                                        # train.py:90
+    best_Us, best_Is = pU.detach().numpy()[su].copy(), pI.detach().numpy()[si].copy()
+    best_sum = np.array([pU.detach().double().sum().item(), pI.detach().double().sum().item()])
+    test_metrics = trainer.evaluate(test_eval, "test")               # train.py:91
+
+    st = trainer.optimizer.state
+    n_train_steps = [len(e["_sizes"]) for e in train_dl.epochs]
+    n_valid_steps = [len(e["_sizes"]) for e in valid_dl.epochs]
+    losses = np.asarray(trainer.loss.values, dtype=np.float64)
+    tl, vl, pos = [], [], 0
+    for a, b in zip(n_train_steps, n_valid_steps):
+        tl.append(losses[pos:pos + a]); pos += a
+        vl.append(losses[pos:pos + b]); pos += b
+
+    def stream_hashes(eps):
+        return np.array([_sha(*(np.concatenate(e[k]) for k in keys)) for e in eps])
+
+    best_epoch = int(np.argmin(log["valid"]))                        # best_metric == 'loss' (base_trainer.py:117-141)
+    valid_users = valid_eval.index.values.astype(np.int64)
+    test_users = test_eval.index.values.astype(np.int64)
+    sel_v = np.flatnonzero(np.isin(valid_users, su))
+    vp_ptr, vp_idx = _csr(list(valid_eval["pos_items"]))
+    vm_ptr, vm_idx = _csr(list(valid_eval["mask_items"]))
+    tp_ptr, tp_idx = _csr(list(test_eval["pos_items"]))
+    tm_ptr, tm_idx = _csr(list(test_eval["mask_items"]))
+    np.savez_compressed(
+        out_path,
+        versions=VERSIONS,
+        frame_names=np.array(list(FULL_FRAME)), frame_values=np.array(list(FULL_FRAME.values()), dtype=np.float64),
+        cfg_names=np.array(["embed_size", "lr", "batch_size", "epochs", "seed", "top_n"]),
+        cfg_values=np.array([embed, lr, batch, epochs, seed, 10], dtype=np.float64),
+        num_users=np.int64(pipe.num_users), num_items=np.int64(pipe.num_items), num_rows=np.int64(len(df)),
+        tsv_sha=np.array(_sha(df.user_id.values, df.business_id.values, df.rating.values)),
+        # split(): row order and list contents (mf_data_pipeline.py:18-52)
+        split_sha=np.array([
+            _sha(train_data["index"].values, train_data.user_id.values, train_data.business_id.values),
+            _sha(valid_data["index"].values, valid_data.user_id.values, valid_data.business_id.values),
+            _sha(valid_users, vp_ptr, vp_idx, vm_ptr, vm_idx),
+            _sha(test_users, tp_ptr, tp_idx, tm_ptr, tm_idx)]),
+        split_rows=np.array([len(train_data), len(valid_data), len(valid_eval), len(test_eval)], dtype=np.int64),
+        train_steps=np.asarray(n_train_steps), valid_steps=np.asarray(n_valid_steps),
+        train_stream_sha=stream_hashes(train_dl.epochs), valid_stream_sha=stream_hashes(valid_dl.epochs),
+        # the first and last batch of the first epoch in clear, to localise a stream mismatch
+        train_first_batch=np.stack([train_dl.epochs[0][k][0] for k in keys]).astype(np.int32),
+        train_last_batch=np.stack([train_dl.epochs[0][k][-1] for k in keys]).astype(np.int32),
+        train_step_loss=np.concatenate(tl), valid_step_loss=np.concatenate(vl),
+        train_epoch_loss=np.asarray(log["train"]), valid_epoch_loss=np.asarray(log["valid"]),
+        valid_metrics=np.asarray(log["metrics"], dtype=np.float64), test_metrics=np.asarray(test_metrics, dtype=np.float64),
+        best_epoch=np.int64(best_epoch),
+        sample_users=su, sample_items=si, init_sum=init_sum, best_sum=best_sum,
+        U0_rows=U0s, I0_rows=I0s,
+        U_rows_epoch=np.stack(log["Us"]), I_rows_epoch=np.stack(log["Is"]),
+        U_rows_best=best_Us, I_rows_best=best_Is,
+        adam_step=np.int64(int(st[pU]["step"])),
+        mU_rows=st[pU]["exp_avg"].numpy()[su], vU_rows=st[pU]["exp_avg_sq"].numpy()[su],
+        mI_rows=st[pI]["exp_avg"].numpy()[si], vI_rows=st[pI]["exp_avg_sq"].numpy()[si],
+        # the reference's own lists: every test user (best model), the sampled users of the last validation
+        top10_test=np.stack(tops["test"]).astype(np.int32),
+        top10_valid_last_rows=sel_v.astype(np.int64),
+        top10_valid_last=np.stack(tops[f"valid{len(log['metrics']) - 1}"])[sel_v].astype(np.int32),
+    )
+    print(f"[mf_full] U={pipe.num_users} I={pipe.num_items} steps={n_train_steps} valid={log['metrics']} "
+          f"test={test_metrics} best_epoch={best_epoch} ({time.time() - t0:.0f} s)")
 
 
 # --------------------------------------------------------------------------- #
@@ -552,6 +704,8 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if "mf" in which:
         golden_mf(os.path.join(HERE, "mf_small.npz"))
+    if "mf_full" in which:                       # ~20 min: only when named (python make_golden.py mf_full)
+        golden_mf_full(os.path.join(HERE, "mf_full.npz"))
     if "ngcf" in which:
         golden_ngcf(os.path.join(HERE, "ngcf_tiny.npz"))
     if "cdae" in which:

@@ -549,6 +549,14 @@ def test_train_lists_from_csr_have_the_reference_law(device, ni):
     other = engine.TrainLists(t(ptr), t(idx), t(users), nu, ni, neg_times, 12, 5, 0.0).loss_dense()[1].cpu().numpy()
     assert (other != neg).any()
     assert (neg[9] != neg[10]).any()                                              # the same user twice: two draws
+    # one batch of a pool is alive at a time: L's storage now holds a later batch, and L says so instead of
+    # handing out another batch's lists; a batch from another pool (what every CDAEBatchLoader owns) is untouched
+    with pytest.raises(engine.EngineError, match="reused by a later batch"):
+        L.loss_dense()
+    own = {}
+    M = engine.TrainLists(t(ptr), t(idx), t(users), nu, ni, neg_times, 11, 5, 0.0, pool=own)
+    engine.TrainLists(t(ptr), t(idx), t(users), nu, ni, neg_times, 13, 5, 0.0)    # class-level pool
+    np.testing.assert_array_equal(M.alive().loss_dense()[1].cpu().numpy(), neg)
     # uniform over the non-positives: 400 seeds on a small catalogue
     small_ptr, small_idx = _csr(rs, 2, 97, [6, 12])
     hits = np.zeros((2, 97))

@@ -55,6 +55,12 @@ def test_argument_checks_without_gpu():
     assert lib.yr_adam_dense(None, None, None, None, 16, 1e-3, 1e-3, 1.0, 0.9, 0.999, 1e-8, 0.0, 0, 0, None) == -2
     assert lib.yr_adam_dense(None, None, None, None, 0, 1e-3, 1e-3, 1.0, 0.9, 0.999, 1e-8, 0.0, 0, 0, None) == 0
     assert lib.yr_topk_masked(None, 1, 10, 10, None, None, None, 0.0, 100, None, None) == -2   # k > 64
+    # yr_adam_dense_dual with row marks: the lanes of a row must share a wave (row_width / 4 divides 64), as
+    # yr_adam_dense_flat requires — 48- and 96-wide rows are refused before any launch (fake aligned addresses)
+    a = 4096
+    for rw in (48, 96, 512):
+        assert lib.yr_adam_dense_dual(a, a, a, a, 4 * rw, a, a, a, a, 4 * rw, rw, a, a, 1e-3, 1e-3, 1.0, 0.9, 0.999,
+                                      1e-8, 0.0, 0, None, 1.0, None, None, None) == -2
     # entry points added in round 2: sizes / helpers answer on the host, bad arguments come back as -2 / -1
     assert lib.yr_bpr_mf_pull_item_buckets(38048, 64) == 2378 and lib.yr_bpr_mf_pull_item_buckets(38048, 48) == -2
     assert lib.yr_cdae_sparse_part_columns(38048) == 1192 and lib.yr_cdae_decode_loss_partials(256, 38048) == 4 * 595
@@ -225,3 +231,24 @@ def test_bf16x3_split_reproduces_f32_products():
     assert np.max(np.abs(six - exact) / scale) < np.max(np.abs(f32 - exact) / scale)
     five = six - u[1] @ i[1].T                                                   # one product fewer is NOT enough
     assert np.max(np.abs(five - exact) / scale) > 2.0 ** -22
+
+
+def test_kernel_resource_budgets_hold_and_the_guard_bites():
+    """scripts/kernel_resources.py (called by __graft_entry__.build()): the register / LDS / scratch figures of the
+    built gfx950 code objects stay inside the occupancy budgets the design depends on (evaluation sweep <= 168 VGPRs:
+    three waves per SIMD; owner passes <= 64 VGPRs and <= 20 KB LDS: every bucket's workgroup resident at once), and
+    the check does fail when a kernel goes over."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import kernel_resources as kr
+    ks = kr.check()
+    sweep = [r for n, r in ks.items() if n.startswith("void yr::mf_eval_topk_kernel<64, 10, false, true, false>")]
+    owner = [r for n, r in ks.items() if n.startswith("void yr::owner_pass_kernel<64, true, true, false, 0>")]
+    assert len(sweep) == 1 and len(owner) == 1 and sweep[0]["vgpr"] <= 168 and owner[0]["vgpr"] <= 64
+    assert sweep[0]["scratch"] == 0 and owner[0]["scratch"] == 0
+    fat = {n: dict(r, vgpr=r["vgpr"] + (24 if "mf_eval_topk_kernel<64, 10, false, true, false>" in n else 0)) for n, r in ks.items()}
+    with pytest.raises(RuntimeError, match="over the budget"):
+        kr.check(fat)
+    spilled = {n: dict(r, scratch=8, spill=2) if "tile_partition_kernel<4>" in n else r for n, r in ks.items()}
+    with pytest.raises(RuntimeError, match="scratch"):
+        kr.check(spilled)

@@ -12,7 +12,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyelprec_engine.so")
+# YR_ENGINE_LIB: measurement hook — an instrumented build of the same sources (scratch/inst_build.sh writes it to
+# a temp directory so that the product objects and library are never overwritten); unset in every product run.
+LIB_PATH = os.environ.get("YR_ENGINE_LIB") or os.path.join(_HERE, "libyelprec_engine.so")
 ENGINE_VERSION = 27
 
 _p = C.c_void_p

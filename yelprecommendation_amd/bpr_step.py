@@ -59,6 +59,7 @@ class BPRMFStep:
         # deterministic: two runs on the same batches give bit-identical tables (always the pull form: the
         # atomic form's float atomics add in arrival order)
         self.deterministic = bool(deterministic)
+        self.skip_collective = False       # measurement only (bench.py: exposed collective time): N > 1 steps without the exchange
         self.item_exchange = item_exchange
         self.rank = int(rank)
         self.split_item_update = split_item_update
@@ -219,8 +220,12 @@ class BPRMFStep:
 
     def _auto_item_order(self, p, n):
         # first pull step: the batch's own occurrence counts stand for the data set's item popularity
-        counts = torch.bincount(p, minlength=self.I.shape[0]) + torch.bincount(n, minlength=self.I.shape[0])
-        self.set_item_order(counts[:self.I.shape[0]])
+        # (ids outside the table are dropped here: the kernels' own range check reports them through the error
+        # flag, on every rank together — a torch error raised from bincount would be rank-local)
+        rows = self.I.shape[0]
+        ids = torch.cat([p, n])
+        ids = ids[(ids >= 0) & (ids < rows)]
+        self.set_item_order(torch.bincount(ids, minlength=rows)[:rows])
 
     def _step_pull(self, u, p, n, record, global_batch, next_batch=None):
         B = u.numel()
@@ -323,8 +328,9 @@ class BPRMFStep:
                         self.betas[0], self.betas[1], self.eps, self.wd, decoupled=self.decoupled, zero_grad=False))
                     self._I_pad[at:at + hi - lo].copy_(self.I[lo:hi])
 
-            reduce_scatter_item_exchange(whole_item_pass, slice_update, self._gI_pad, self._I_pad, sl, self.pg, overlap)
-            if self.world_size > 1:
+            reduce_scatter_item_exchange(whole_item_pass, slice_update, self._gI_pad, self._I_pad, sl, self.pg, overlap,
+                                         collective=not self.skip_collective)
+            if self.world_size > 1 and not self.skip_collective:
                 self.I.copy_(self._I_pad[:rows])
             self._gI_dirty = True
             self.U, self._U_alt = self._U_alt, self.U
@@ -332,7 +338,7 @@ class BPRMFStep:
         steps = [local_first] + [make_chunk(c) for c in range(1, nchunks)]
         grads = [self.gI[bounds[c]:bounds[c + 1]] for c in range(nchunks)] if multi else [None]
         sharded_item_exchange(steps, [make_update(c) for c in range(nchunks)], grads, self.pg, self.world_size,
-                              overlap)
+                              overlap, collective=not self.skip_collective)
         self._gI_dirty = multi
         self.U, self._U_alt = self._U_alt, self.U
 
@@ -374,8 +380,9 @@ class BPRMFStep:
                 engine.check(rc, "yr_bpr_mf_fwd_bwd")
 
         self._timed("bpr_fwd_bwd", B * (24 + 24 * D), record, fwd_bwd)
-        import torch.distributed as dist
-        dist.all_reduce(self.gI, op=dist.ReduceOp.SUM, group=self.pg)
+        if not self.skip_collective:
+            import torch.distributed as dist
+            dist.all_reduce(self.gI, op=dist.ReduceOp.SUM, group=self.pg)
 
         def adam():
             rc = lib.yr_adam_dense_dual(pU, pgU, self._pmU, self._pvU, nU * D, self._pI, pgI, self._pmI, self._pvI,

@@ -184,6 +184,7 @@ class CDAEStep:
             raise NotImplementedError("step_lists needs the sampled decoder (NS-BCE)")
         if lists.B == 0:
             return
+        lists.alive()
         self._buffers(lists.B)
         self._run(user_id.contiguous(), lists.rows, lists.loss, None, None)
 

@@ -67,7 +67,6 @@ constexpr int kEtMaxK = 32;
 #endif
 constexpr int kEtFlushAt = YR_ET_FLUSH_AT;             // flush when some lane holds more than this
 constexpr int kEtCheckEvery = YR_ET_CHECK_EVERY;       // ... checked after this many accumulator registers
-constexpr int kEtBufCap = kEtFlushAt + kEtCheckEvery;
 
 #ifdef YR_ET_STAMPS
 // -DYR_ET_STAMPS: shader-clock cycles every wave spends per phase (scratch/eval_phases.sh), summed over the waves

@@ -294,7 +294,10 @@ extern "C" int yr_adam_dense_dual(float* p0, float* g0, float* m0, float* v0, in
   if (!aligned16(p0) || !aligned16(g0) || !aligned16(m0) || !aligned16(v0) || !aligned16(p1) || !aligned16(g1) ||
       !aligned16(m1) || !aligned16(v1))
     return YR_ERR_BADARG;
-  if ((touched0 || touched1) && (row_width <= 0 || (row_width & 3) || n0 % row_width || n1 % row_width))
+  // a row's mark is read by all row_width / 4 lanes of the row and cleared by the first of them: the lanes of a
+  // row must sit in ONE wave (row_width / 4 divides 64), as yr_adam_dense_flat requires
+  if ((touched0 || touched1) && (row_width <= 0 || (row_width & 3) || n0 % row_width || n1 % row_width ||
+                                 row_width / 4 > kWave || kWave % (row_width / 4)))
     return YR_ERR_BADARG;
   DualAdam t;
   t.p0 = (float4*)p0; t.g0 = (float4*)g0; t.m0 = (float4*)m0; t.v0 = (float4*)v0;

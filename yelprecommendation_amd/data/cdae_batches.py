@@ -140,6 +140,7 @@ class CDAEBatchLoader:
         self._gen = torch.Generator(device=data.device).manual_seed(seed)
         self._seeds = torch.Generator().manual_seed(seed)          # host generator: per-batch kernel seeds
         self._flag = engine.new_error_flag(data.device) if data.device.type == "cuda" else None   # cpu store: iterating raises
+        self._list_pool = {}                                       # this loader's TrainLists storage (one batch alive at a time)
 
     def __len__(self):
         return (self.data.num_users + self.batch_size - 1) // self.batch_size
@@ -169,7 +170,7 @@ class CDAEBatchLoader:
                 made = engine.TrainLists(ptr, idx, users.contiguous(), d.num_users, d.num_items,
                                          0 if self.mode == "test" else self.neg_times, seeds[0], seeds[1],
                                          self.dropout if self.mode == "train" else 0.0, err_flag=self._flag,
-                                         extra=d.csr("valid") if self.mode == "valid" else None)
+                                         extra=d.csr("valid") if self.mode == "valid" else None, pool=self._list_pool)
                 batch = {"user_id": users, "lists": made}
                 if self.mode != "train":
                     batch["item_lists"] = lists

@@ -396,24 +396,33 @@ class TrainLists:
     """A CDAE training batch as lists (yr_cdae_train_lists): ``rows`` — the encoder's input, a SparseRows of
     dropout_p(train items) — and ``loss`` — (columns, targets, counts) of the NS-BCE positions (positives +
     sampled negatives).  The buffers are sized for the worst case once per (device, B, I) and reused by the
-    next batch (one batch at a time is alive, like SparseRows)."""
+    next batch made from the same ``pool`` — ONE batch of a pool is alive at a time: the next one overwrites the
+    storage, and a consumer handed a batch that is no longer the pool's latest gets an EngineError from
+    :meth:`alive` (CDAEStep.step_lists, CDAETrainer._scored_by_lists and loss_dense call it) instead of silently
+    reading another batch's lists.  Every CDAEBatchLoader owns its pool, so the train / valid / test loaders do
+    not alias each other; without ``pool`` a class-level one is used."""
     _pool = {}
 
     def __init__(self, ptr, idx, users, num_users, num_items, neg_times, neg_seed, drop_seed, p, err_flag=None,
-                 extra=None):
+                 extra=None, pool=None):
         """``extra``: (ptr, idx) of a second per-user CSR whose items are positives of the loss list too (the
         held-out items in validation) without entering the encoder list."""
         lib = _lib.load()
         B, I = users.numel(), int(num_items)
         dev = users.device
         key = (dev, B, I)
-        buf = TrainLists._pool.get(key)
-        if buf is None:
+        pool = TrainLists._pool if pool is None else pool
+        slot = pool.get(key)
+        if slot is None:
             n, parts = B * SPARSE_PARTS * sparse_part_columns(I), B * SPARSE_PARTS
             mk = lambda m, dt: torch.empty(m, dtype=dt, device=dev)
-            buf = (mk(n, torch.int32), mk(n, torch.float32), mk(parts, torch.int32),
-                   mk(n, torch.int32), mk(n, torch.float32), mk(parts, torch.int32))
-            TrainLists._pool = {key: buf}
+            slot = [(mk(n, torch.int32), mk(n, torch.float32), mk(parts, torch.int32),
+                     mk(n, torch.int32), mk(n, torch.float32), mk(parts, torch.int32)), 0]
+            pool.clear()                                # a batch of the old shape keeps its own references
+            pool[key] = slot
+        slot[1] += 1
+        self._slot, self._generation = slot, slot[1]
+        buf = slot[0]
         i64 = torch.int64
         some = lambda t: t if t.numel() else torch.zeros(1, dtype=i64, device=dev)   # an empty index: never read, needs an address
         check(lib.yr_cdae_train_lists(_dev(ptr, i64, "ptr"), _dev(some(idx), i64, "idx"),
@@ -426,8 +435,16 @@ class TrainLists:
         self.loss = (buf[3], buf[4], buf[5])
         self.B, self.I = B, I
 
+    def alive(self):
+        """Raise when a later batch of the same pool has overwritten this batch's storage."""
+        if self._slot[1] != self._generation:
+            raise EngineError("TrainLists: this batch's buffers were reused by a later batch of the same loader "
+                              "(one batch of a loader is alive at a time; consume it before fetching the next)")
+        return self
+
     def loss_dense(self):
         """(target, negative_mask) [B, I] the loss lists stand for (tests)."""
+        self.alive()
         t = SparseRows.from_buffers(self.loss[0], self.loss[1] + 1.0, self.loss[2], self.B, self.I).to_dense()
         return (t == 2.0).float(), (t == 1.0).float()
 

@@ -126,7 +126,7 @@ class CDAETrainer(BaseTrainer):
         count = torch.zeros(engine.COUNT_WORDS, dtype=torch.int32, device=dev)
         partials = None
         for data in dataloader:
-            users, lists = data['user_id'].to(dev).contiguous(), data['lists']
+            users, lists = data['user_id'].to(dev).contiguous(), data['lists'].alive()
             z = engine.cdae_sparse_encode(lists.rows, Wh, bh, V, users, model._hidden_act, err_flag=model._flag())
             Z.index_copy_(0, users, z)
             covered += users.numel()

@@ -66,7 +66,8 @@ def _as_list(x):
     return list(x) if isinstance(x, (list, tuple)) else [x]
 
 
-def reduce_scatter_item_exchange(local_step, slice_update, grad_padded, param_padded, slices, group=None, overlap=None):
+def reduce_scatter_item_exchange(local_step, slice_update, grad_padded, param_padded, slices, group=None, overlap=None,
+                                 collective=True):
     """The other form of the exchange (one chunk): every rank keeps the Adam state of ONE slice of the item
     rows only.
 
@@ -82,10 +83,11 @@ def reduce_scatter_item_exchange(local_step, slice_update, grad_padded, param_pa
 
     Same wire volume as the ring all-reduce (2 (N-1)/N of the table per rank).  RCCL:
     reduce_scatter_tensor / all_gather_into_tensor; backends without reduce-scatter (gloo in the CPU
-    tests) take all_reduce + the own slice, and all_gather over the slice list."""
+    tests) take all_reduce + the own slice, and all_gather over the slice list.
+    ``collective=False`` (measurement only, see sharded_item_exchange): both collectives are skipped."""
     import torch.distributed as dist
     local_step()
-    w, per, r = slices.world_size, slices.per, slices.rank
+    w, per, r = slices.world_size if collective else 1, slices.per, slices.rank
     mine = grad_padded[r * per:(r + 1) * per]
     if w > 1:
         if dist.get_backend(group) == "nccl":
@@ -104,7 +106,7 @@ def reduce_scatter_item_exchange(local_step, slice_update, grad_padded, param_pa
             dist.all_gather(parts, own.clone(), group=group)
 
 
-def sharded_item_exchange(local_step, item_update, grad_item, group=None, world_size=1, overlap=None):
+def sharded_item_exchange(local_step, item_update, grad_item, group=None, world_size=1, overlap=None, collective=True):
     """The exchange step of the user-sharded BPR-MF step, backend-agnostic.
     Each of ``local_step``, ``item_update``, ``grad_item`` is one object or a list of C chunks
     (chunk c covers a contiguous range of item rows):
@@ -123,6 +125,9 @@ def sharded_item_exchange(local_step, item_update, grad_item, group=None, world_
 
     ``bpr_step.BPRMFStep`` passes HIP-kernel closures; the CPU tests pass oracle closures to check
     that the sharded protocol reproduces the single-process step.
+    ``collective=False`` — MEASUREMENT ONLY (bench.py's ``collective.exposed_us``): the same launches without the
+    all-reduce, so that the step's time with and without the collective can be compared; the result is then the
+    rank-local update, not the step.
     """
     steps, updates, grads = _as_list(local_step), _as_list(item_update), _as_list(grad_item)
     if not (len(steps) == len(updates) == len(grads)):
@@ -130,7 +135,7 @@ def sharded_item_exchange(local_step, item_update, grad_item, group=None, world_
     works = []
     for fn, g in zip(steps, grads):
         fn()
-        if world_size > 1:
+        if world_size > 1 and collective:
             import torch.distributed as dist
             works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True))
     if overlap is not None:
