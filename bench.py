@@ -135,20 +135,33 @@ def other_workload(args):
         from yelprecommendation_amd.utils import make_config
         r = torch.randint(1, 6, u.shape, device=dev)
         graph = LaplacianCSR.from_interactions(u.cpu().numpy(), i.cpu().numpy(), r.cpu().numpy(), NU, NI, dev)
-        model = NGCF(make_config("NGCF", embed_size=DIM, num_orders=3, device="cuda", model_dir="/tmp/yr_bench"), NU, NI).to(dev)
+        cfg = make_config("NGCF", embed_size=DIM, num_orders=3, device="cuda", model_dir="/tmp/yr_bench")
+        model = NGCF(cfg, NU, NI).to(dev)
         opt, lossf = Adam(model.parameters(), lr=1e-4), BPRLoss()
         B = 4096
-        bu, bp, bn = (torch.randint(0, n, (B,), device=dev) for n in (NU, NI, NI))
+        # batches as a loader over the train rows yields them: (user, one of its items, uniform negative)
+        pick = torch.randint(0, u.numel(), (B,), device=dev)
+        bu, bp, bn = u[pick].contiguous(), i[pick].contiguous(), torch.randint(0, NI, (B,), device=dev)
 
-        def step():
-            pos, neg = model.bpr_forward(bu, bp, bn, graph)
-            opt.zero_grad(); lossf(pos, neg).backward(); opt.step()
-        dt = timed(step)
+        def make_step(b):
+            def step():
+                pos, neg = model.bpr_forward(bu[:b], bp[:b], bn[:b], graph)
+                opt.zero_grad(); lossf(pos, neg).backward(); opt.step()
+            return step
+        dt = timed(make_step(B))
+        # batch-aware propagation (layer k on the rows the batch's scores need) vs the reference's shape (the whole
+        # graph for every batch, cfg.ngcf_subset_fraction = 0), at the reference's default batch and at 4,096
+        step_ms = {"4096": round(dt * 1e3, 4), "32": round(timed(make_step(32)) * 1e3, 4)}
+        cfg.ngcf_subset_fraction = 0.0
+        step_ms["4096_whole_graph"] = round(timed(make_step(B)) * 1e3, 4)
+        step_ms["32_whole_graph"] = round(timed(make_step(32)) * 1e3, 4)
+        cfg.ngcf_subset_fraction = 0.5
         X = model.embedding.weight.detach()
         t_spmm = timed(lambda: engine.spmm_csr(graph, X))
         alg = graph.nnz * 8 + (graph.n + 1) * 4 + 2 * graph.n * DIM * 4      # CSR + read E + write Z
         out.update(metric="NGCF 3-layer full-graph train step @ dim64", value=round(dt * 1e3, 4), ms_per_step=round(dt * 1e3, 4),
                    config={"workload": "NGCF K=3, 69,716 nodes, %d non-zeros, batch 4096" % graph.nnz},
+                   step_ms=step_ms,
                    roofline={"bound": "hbm", "kernel": "spmm_csr_kernel (6 launches per step)",
                              "achieved": round(alg / t_spmm / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(alg / t_spmm / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define YR_ENGINE_VERSION 27
+#define YR_ENGINE_VERSION 28
 
 #define YR_ERR_UNSUPPORTED (-1) /* embedding width / option not compiled in   */
 #define YR_ERR_BADARG      (-2) /* null pointer, negative size, misalignment  */
@@ -271,6 +271,44 @@ int yr_ngcf_dense_bwd_data(const float *dEout, const float *Eout, const float *E
                            float *dZ, float *dE, void *stream);
 int yr_ngcf_dense_bwd_weight(const float *dEout, const float *Eout, const float *E, const float *Z,
                              int64_t n, int D, float *dW1, float *dW2, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * NGCF, batch-aware propagation (ABI v28).  The reference propagates the WHOLE graph for every batch
+ * (trainers/ngcf_trainer.py:102-117 -> models/ngcf.py:30-45) although bpr_forward reads layer K at the batch's
+ * rows only (models/ngcf.py:37-39: last[u], last[U + p], last[U + n]).  With S_K = those rows and
+ * S_{k-1} = S_k + neighbours(S_k), layer k is needed on S_k alone; these entry points compute exactly that and
+ * give, on the rows they compute, bit-identical results to the full-graph entry points above.
+ *
+ * yr_ngcf_frontier_mark: flags[0 .. num_users + num_items) = 0, then 1 at user[b], num_users + pos[b] and (neg may
+ *   be NULL) num_users + neg[b] for every b < B; out-of-range ids are skipped (yr_ngcf_score_fwd reports them).
+ * yr_ngcf_frontier_expand: flags_out = flags_in + neighbours (rows of the CSR) of every flagged row.
+ * yr_ngcf_frontier_list: rows[0 .. *count) = the flagged rows (in no particular order), *count on the DEVICE (the
+ *   host never waits for it); rows must hold n entries.
+ * yr_spmm_csr_subset: yr_spmm_csr restricted to the rows with row_active[row] != 0 (other rows of Y untouched;
+ *   NULL = all rows) and, with col_active, to the neighbours with col_active[col] != 0 — the backward product
+ *   dE += L dZ where dZ is non-zero on a known row set only.
+ * yr_ngcf_dense_{fwd,bwd_data,bwd_weight}_rows: the dense part of a layer over the rows rows[0 .. *count) instead
+ *   of 0 .. n-1; max_rows (<= n) is the host's upper bound of *count and only sizes the grid (the workgroups
+ *   stride over the list, so any count up to n is covered).
+ * ------------------------------------------------------------------------- */
+int yr_ngcf_frontier_mark(const int64_t *user, const int64_t *pos, const int64_t *neg, int64_t B,
+                          int64_t num_users, int64_t num_items, uint8_t *flags, void *stream);
+int yr_ngcf_frontier_expand(const int32_t *rowptr, const int32_t *col, int64_t n,
+                            const uint8_t *flags_in, uint8_t *flags_out, void *stream);
+int yr_ngcf_frontier_list(const uint8_t *flags, int64_t n, int32_t *rows, int32_t *count, void *stream);
+int yr_spmm_csr_subset(const int32_t *rowptr, const int32_t *col, const float *val,
+                       const float *X, float *Y, int64_t n, int D, int accumulate,
+                       const int32_t *heavy_rows, int64_t n_heavy, int heavy_threshold,
+                       const uint8_t *row_active, const uint8_t *col_active, void *stream);
+int yr_ngcf_dense_fwd_rows(const float *E, const float *Z, const float *W1, const float *W2,
+                           int64_t n, int D, float *Eout,
+                           const int32_t *rows, const int32_t *count, int64_t max_rows, void *stream);
+int yr_ngcf_dense_bwd_data_rows(const float *dEout, const float *Eout, const float *E, const float *Z,
+                                const float *W1T, const float *W2T, int64_t n, int D, float *dZ, float *dE,
+                                const int32_t *rows, const int32_t *count, int64_t max_rows, void *stream);
+int yr_ngcf_dense_bwd_weight_rows(const float *dEout, const float *Eout, const float *E, const float *Z,
+                                  int64_t n, int D, float *dW1, float *dW2,
+                                  const int32_t *rows, const int32_t *count, int64_t max_rows, void *stream);
 
 /* ---------------------------------------------------------------------------
  * CDAE                        (reference models/cdae.py:46-52, loss.py:12-16 and their autograd)

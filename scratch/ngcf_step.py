@@ -1,0 +1,43 @@
+"""Full-size NGCF train step (K = 3, Yelp2018 shape): wall time per step for a batch size and a subset fraction.
+usage: python scratch/ngcf_step.py <batch> <fraction> [steps]   (under rocprofv3 --kernel-trace --stats for kernel sums)"""
+import sys, time
+import torch
+sys.path.insert(0, ".")
+from yelprecommendation_amd.data.synthetic import YELP2018_ITEMS as NI, YELP2018_USERS as NU, make_interactions_torch
+from yelprecommendation_amd.graph import LaplacianCSR
+from yelprecommendation_amd.loss import BPRLoss
+from yelprecommendation_amd.models.ngcf import NGCF
+from yelprecommendation_amd.optim import Adam
+from yelprecommendation_amd.utils import make_config
+
+B, frac = int(sys.argv[1]), float(sys.argv[2])
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+dev = torch.device("cuda", 0)
+u, i = make_interactions_torch(NU, NI, 47.0, seed=1234, device=dev)
+r = torch.randint(1, 6, u.shape, device=dev)
+graph = LaplacianCSR.from_interactions(u.cpu().numpy(), i.cpu().numpy(), r.cpu().numpy(), NU, NI, dev)
+cfg = make_config("NGCF", embed_size=64, num_orders=3, device="cuda", model_dir="/tmp/yr_bench", ngcf_subset_fraction=frac)
+model = NGCF(cfg, NU, NI).to(dev)
+opt, lossf = Adam(model.parameters(), lr=1e-4), BPRLoss()
+pick = torch.randint(0, u.numel(), (B,), device=dev)
+bu, bp, bn = u[pick].contiguous(), i[pick].contiguous(), torch.randint(0, NI, (B,), device=dev)
+
+
+def step():
+    pos, neg = model.bpr_forward(bu, bp, bn, graph)
+    opt.zero_grad(); lossf(pos, neg).backward(); opt.step()
+
+
+for _ in range(10):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    step()
+t_host = (time.perf_counter() - t0) / steps          # enqueue time (the host's share)
+torch.cuda.synchronize()
+t = (time.perf_counter() - t0) / steps
+from yelprecommendation_amd.models import ngcf as m
+sets = m._subset_plan(graph, NU, 3, bu, bp, bn, frac)
+sizes = [None if s is None else int(s.count.item()) for s in sets]
+print(f"B={B} fraction={frac}: {t*1e3:.4f} ms per step (host enqueue {t_host*1e3:.4f} ms), set sizes per layer {sizes} of {graph.n}")

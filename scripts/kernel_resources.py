@@ -28,7 +28,12 @@ BUDGETS = [
     (r"void yr::owner_pass_kernel<64, (true|false)", 64, 20 * 1024,
      "every bucket's workgroup resident at once: 8 workgroups of 256 threads per CU = 64 VGPRs, <= 20 KB LDS"),
     (r"void yr::owner_pass_kernel<(16|32|128), (true|false)", 64, 20 * 1024, "as above for the other widths"),
-    (r"void yr::spmm_csr_kernel<64, (true|false)>", 96, 0, "one wave per row with 8 gather passes in flight: five waves per SIMD"),
+    (r"void yr::spmm_csr_kernel<64, (true|false), (true|false)>", 96, 0,
+     "one wave per row with 8 gather passes in flight: five waves per SIMD (full and row-subset forms)"),
+    (r"void yr::ngcf_dense_fwd_kernel<64, false>", 128, 0, "one wave per workgroup, four waves per SIMD"),
+    (r"void yr::ngcf_dense_bwd_data_kernel<64, false>", 128, 0, "as the forward kernel"),
+    (r"void yr::ngcf_dense_(fwd|bwd_data)_kernel<64, true>", 168, 0,
+     "row-list forms: three waves per SIMD (a hoisted weight tile once took the forward kernel to 252)"),
 ]
 # Scratch (spilled registers) per lane.  The forms the benchmark and the trainers run by default — width 64, summation
 # order free — must have none; the deterministic-order forms and some forms of the other widths are held at 64 VGPRs by

@@ -316,3 +316,111 @@ def test_full_size_spmm_properties(device):
     acc = y.clone()
     engine.spmm_csr(graph, x, out=acc, accumulate=True, form="sliced")
     torch.testing.assert_close(acc, y + Lx, rtol=1e-5, atol=1e-5)
+
+
+def test_frontier_and_subset_kernels(device):
+    """The batch-aware propagation's building blocks (ABI v28): frontier flags == the NumPy definition
+    S_K = {u, U + p, U + n}, S_{k-1} = S_k + neighbours(S_k); the row list is a permutation of the flagged rows with
+    its length on the device; the row-subset SpMM writes EXACTLY the full product's rows (bit for bit) and nothing
+    else; with the column filter it equals the product of a matrix whose unflagged rows are zero; the row-list
+    forms of the dense kernels equal the full kernels on the listed rows bit for bit."""
+    from yelprecommendation_amd import engine
+    from yelprecommendation_amd.graph import LaplacianCSR, laplacian_scipy
+    rs = np.random.RandomState(11)
+    nu, ni, d = 900, 700, 64
+    u, i, r = _random_graph(rs, nu, ni, 6, hot_items=4)
+    L = laplacian_scipy(u, i, r, nu, ni)
+    graph = LaplacianCSR.from_scipy(L, device, heavy_threshold=64)
+    assert graph.n_heavy >= 1
+    n = nu + ni
+    t = lambda a: torch.from_numpy(a).to(device)
+    bu, bp, bn = rs.randint(0, nu, 40), rs.randint(0, ni, 40), rs.randint(0, ni, 40)
+    bp[:3] = (0, 1, 2)                                              # the heavy rows are in the batch
+    want0 = np.zeros(n, np.uint8)
+    want0[bu] = 1; want0[nu + bp] = 1; want0[nu + bn] = 1
+    f0 = engine.ngcf_frontier_mark(nu, ni, t(bu), t(bp), t(bn))
+    np.testing.assert_array_equal(f0.cpu().numpy(), want0)
+    only_pos = engine.ngcf_frontier_mark(nu, ni, t(bu), t(bp), None).cpu().numpy()
+    assert only_pos.sum() == len(set(bu.tolist())) + len(set(bp.tolist()))
+    adj = (abs(L) > 0).astype(np.int32)
+    want1 = ((adj @ want0.astype(np.int32) > 0) | (want0 > 0)).astype(np.uint8)
+    f1 = engine.ngcf_frontier_expand(graph, f0)
+    np.testing.assert_array_equal(f1.cpu().numpy(), want1)
+    s0 = engine.NGCFRowSet(f0, 3 * 40)
+    cnt = int(s0.count.item())
+    assert cnt == int(want0.sum()) and sorted(s0.rows[:cnt].cpu().tolist()) == np.flatnonzero(want0).tolist()
+    # SpMM, row subset
+    X = t(rs.standard_normal((n, d)).astype(np.float32))
+    full = engine.spmm_csr(graph, X)
+    sub = engine.spmm_csr_subset(graph, X, torch.full_like(X, 7.0), row_active=f0)
+    on = f0.bool()
+    assert torch.equal(sub[on], full[on]) and bool((sub[~on] == 7.0).all())
+    # ... + column filter == the product with the unflagged rows of X zeroed; accumulate adds to what is there
+    Xz = X * f1.float()[:, None]
+    want = engine.spmm_csr(graph, Xz)
+    got = engine.spmm_csr_subset(graph, X, torch.zeros_like(X), row_active=None, col_active=f1)
+    assert torch.equal(got, want)
+    acc = engine.spmm_csr_subset(graph, X, torch.ones_like(X), row_active=f0, col_active=f1, accumulate=True)
+    ref = engine.spmm_csr(graph, Xz, out=torch.ones_like(X), accumulate=True)
+    assert torch.equal(acc[on], ref[on]) and bool((acc[~on] == 1.0).all())
+    # dense part over the row list
+    E, Z = X, full
+    W1, W2 = (t((rs.standard_normal((d, d)) * 0.2).astype(np.float32)) for _ in range(2))
+    out_full = engine.ngcf_dense_fwd(E, Z, W1, W2)
+    out_sub = engine.ngcf_dense_fwd(E, Z, W1, W2, out=torch.full_like(E, 5.0), rows=s0)
+    assert torch.equal(out_sub[on], out_full[on]) and bool((out_sub[~on] == 5.0).all())
+    dEout = torch.zeros_like(E)
+    dEout[on] = t(rs.standard_normal((cnt, d)).astype(np.float32))
+    dE_f, dW1_f, dW2_f = torch.zeros_like(E), torch.zeros_like(W1), torch.zeros_like(W2)
+    dZ_f = engine.ngcf_dense_bwd(dEout, out_full, E, Z, W1, W2, dE_f, dW1_f, dW2_f)
+    dE_s, dW1_s, dW2_s = torch.zeros_like(E), torch.zeros_like(W1), torch.zeros_like(W2)
+    dZ_s = engine.ngcf_dense_bwd(dEout, out_full, E, Z, W1, W2, dE_s, dW1_s, dW2_s, dZ=torch.full_like(E, 3.0), rows=s0)
+    assert torch.equal(dZ_s[on], dZ_f[on]) and bool((dZ_s[~on] == 3.0).all()) and torch.equal(dE_s, dE_f)
+    torch.testing.assert_close(dW1_s, dW1_f, rtol=1e-4, atol=1e-5)      # float atomics / another chunking of the rows
+    torch.testing.assert_close(dW2_s, dW2_f, rtol=1e-4, atol=1e-5)
+    # an empty batch: no flags, an empty list, nothing computed
+    e = torch.zeros(0, dtype=torch.int64, device=device)
+    fe = engine.ngcf_frontier_mark(nu, ni, e, e, e)
+    se = engine.NGCFRowSet(fe, 0)
+    assert int(fe.sum()) == 0 and int(se.count.item()) == 0
+    assert bool((engine.ngcf_dense_fwd(E, Z, W1, W2, out=torch.full_like(E, 5.0), rows=se) == 5.0).all())
+
+
+@pytest.mark.parametrize("batch,fraction,subset_layers", [(12, 0.5, 2), (400, 0.5, 1), (12, 1e9, 3), (5000, 0.5, 0)])
+def test_batch_aware_propagation_equals_full_graph_propagation(device, tmp_path, batch, fraction, subset_layers):
+    """NGCF.bpr_forward / forward propagate layer k on the rows the batch's scores need (cfg.ngcf_subset_fraction,
+    default 0.5) instead of the whole graph for every batch (reference trainers/ngcf_trainer.py:108 ->
+    models/ngcf.py:30-45): the scores are BIT-IDENTICAL to the full-graph propagation's, the loss too, and every
+    parameter gradient agrees to summation order — for a small batch (last two of three layers restricted), a
+    medium one (last layer only), all layers forced, and a batch whose rows cover the graph (none restricted)."""
+    from yelprecommendation_amd.graph import LaplacianCSR
+    from yelprecommendation_amd.loss import BPRLoss
+    from yelprecommendation_amd.models import ngcf as mngcf
+    from yelprecommendation_amd.models.ngcf import NGCF
+    from yelprecommendation_amd.utils import make_config
+    rs = np.random.RandomState(batch)
+    nu, ni = 2500, 2100
+    u, i, r = _random_graph(rs, nu, ni, 9, hot_items=5)
+    graph = LaplacianCSR.from_interactions(u, i, r, nu, ni, device, heavy_threshold=128)
+    bu, bp, bn = (torch.from_numpy(rs.randint(0, m, batch)).to(device) for m in (nu, ni, ni))
+    plan = mngcf._subset_plan(graph, nu, 3, bu, bp, bn, fraction)
+    assert sum(s is not None for s in plan) == subset_layers and all(s is None for s in plan[:3 - subset_layers])
+    res = {}
+    for frac in (fraction, 0.0):
+        torch.manual_seed(5)
+        model = NGCF(make_config("NGCF", embed_size=64, num_orders=3, device="cuda", model_dir=str(tmp_path),
+                                 ngcf_subset_fraction=frac), nu, ni).to(device)
+        pos, neg = model.bpr_forward(bu, bp, bn, graph)
+        loss = BPRLoss()(pos, neg)
+        loss.backward()
+        single = model.forward(bu, bp, graph)
+        model.check_indices()
+        res[frac] = (pos.detach(), neg.detach(), loss.detach(), single.detach(),
+                     {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    a, b = res[fraction], res[0.0]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    assert torch.equal(a[3], a[0])                                   # forward(u, i) == bpr_forward's positive scores
+    for k in a[4]:
+        scale = float(b[4][k].abs().max())
+        torch.testing.assert_close(a[4][k], b[4][k], rtol=2e-4, atol=2e-6 * scale, msg=lambda m: f"{k}: {m}")
+    assert float(a[4]["embedding.weight"].abs().sum()) > 0

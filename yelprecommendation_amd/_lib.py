@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # YR_ENGINE_LIB: measurement hook — an instrumented build of the same sources (scratch/inst_build.sh writes it to
 # a temp directory so that the product objects and library are never overwritten); unset in every product run.
 LIB_PATH = os.environ.get("YR_ENGINE_LIB") or os.path.join(_HERE, "libyelprec_engine.so")
-ENGINE_VERSION = 27
+ENGINE_VERSION = 28
 
 _p = C.c_void_p
 _i64 = C.c_int64
@@ -44,6 +44,13 @@ SIGNATURES = {
     "yr_ngcf_dense_fwd": [_p, _p, _p, _p, _i64, _int, _p, _p],
     "yr_ngcf_dense_bwd_data": [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p],
     "yr_ngcf_dense_bwd_weight": [_p, _p, _p, _p, _i64, _int, _p, _p, _p],
+    "yr_ngcf_frontier_mark": [_p, _p, _p, _i64, _i64, _i64, _p, _p],
+    "yr_ngcf_frontier_expand": [_p, _p, _i64, _p, _p, _p],
+    "yr_ngcf_frontier_list": [_p, _i64, _p, _p, _p],
+    "yr_spmm_csr_subset": [_p, _p, _p, _p, _p, _i64, _int, _int, _p, _i64, _int, _p, _p, _p],
+    "yr_ngcf_dense_fwd_rows": [_p, _p, _p, _p, _i64, _int, _p, _p, _p, _i64, _p],
+    "yr_ngcf_dense_bwd_data_rows": [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p, _p, _i64, _p],
+    "yr_ngcf_dense_bwd_weight_rows": [_p, _p, _p, _p, _i64, _int, _p, _p, _p, _p, _i64, _p],
     "yr_gemm_f32": [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _int, _int, _int, _p],
     "yr_gemm_f32_ex": [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _int, _int, _int, _p, _p, _p],
     "yr_cdae_decode_loss_partials": [_i64, _i64],

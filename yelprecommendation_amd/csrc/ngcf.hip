@@ -33,10 +33,14 @@ constexpr int kSpmmHeavyBlocks = 256;
 // One lane group's share of a CSR row: neighbours lo+first, lo+first+step, ...  The column/value
 // pairs of the NEXT round are fetched before this round's rows are gathered (two dependent
 // latencies per round otherwise), and slots past the row end issue no row load at all.
-template <int D>
+// CF (column filter, the row-subset form below): a neighbour whose `col_active` byte is 0 is skipped like a slot
+// past the row end — its row of X is known to be all zero (or not computed) and is never fetched.  The flag is
+// read where the column index is, one round ahead of the gather.
+template <int D, bool CF = false>
 __device__ __forceinline__ void spmm_accumulate(const int32_t* __restrict__ col, const float* __restrict__ val,
                                                 const float* __restrict__ Xl /* X + this lane's 4 floats */, int lo,
-                                                int hi, int first, int step, float4& acc) {
+                                                int hi, int first, int step, float4& acc,
+                                                const uint8_t* __restrict__ col_active = nullptr) {
   int c[kSpmmUnroll];
   float w[kSpmmUnroll];
 #pragma unroll
@@ -45,6 +49,7 @@ __device__ __forceinline__ void spmm_accumulate(const int32_t* __restrict__ col,
     const bool ok = idx < hi;
     c[q] = ok ? col[idx] : -1;
     w[q] = ok ? val[idx] : 0.0f;
+    if (CF && ok && !col_active[c[q]]) c[q] = -1;
   }
   for (int base = lo; base < hi; base += step * kSpmmUnroll) {
     float4 r[kSpmmUnroll];
@@ -61,6 +66,7 @@ __device__ __forceinline__ void spmm_accumulate(const int32_t* __restrict__ col,
       const bool ok = idx < hi;
       c[q] = ok ? col[idx] : -1;
       w[q] = ok ? val[idx] : 0.0f;
+      if (CF && ok && !col_active[c[q]]) c[q] = -1;
     }
 #pragma unroll
     for (int q = 0; q < kSpmmUnroll; ++q) {
@@ -70,13 +76,18 @@ __device__ __forceinline__ void spmm_accumulate(const int32_t* __restrict__ col,
   }
 }
 
-template <int D, bool ACCUM>
+// SUB (row-subset form, yr_spmm_csr_subset): only the rows whose `row_active` byte is set are computed (the others
+// are left untouched), and with `col_active` only the neighbours whose byte is set are gathered.  A computed row
+// goes through exactly the instructions of the full form, so its result is bit-identical to the full product's
+// whenever the skipped neighbours' rows of X are zero (or, forward: every neighbour is active).
+template <int D, bool ACCUM, bool SUB = false>
 __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int32_t* __restrict__ rowptr,
                                                           const int32_t* __restrict__ col,
                                                           const float* __restrict__ val,
                                                           const float* __restrict__ X, float* __restrict__ Y,
                                                           int n, const int32_t* __restrict__ heavy, int n_heavy,
-                                                          int heavy_t) {
+                                                          int heavy_t, const uint8_t* __restrict__ row_active = nullptr,
+                                                          const uint8_t* __restrict__ col_active = nullptr) {
   constexpr int LPR = D / 4, GPW = kWave / LPR;
   __shared__ float4 s_acc[kWavesPerBlock][LPR];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -84,8 +95,13 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int32_t* __restr
   if ((int)blockIdx.x < kSpmmHeavyBlocks) {
     for (int h = blockIdx.x; h < n_heavy; h += kSpmmHeavyBlocks) {
       const int row = heavy[h];
+      if (SUB && row_active && !row_active[row]) continue;          // workgroup-uniform
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      spmm_accumulate<D>(col, val, X + 4 * l, rowptr[row], rowptr[row + 1], wave * GPW + grp, kWavesPerBlock * GPW, acc);
+      if (SUB && col_active)
+        spmm_accumulate<D, true>(col, val, X + 4 * l, rowptr[row], rowptr[row + 1], wave * GPW + grp,
+                                 kWavesPerBlock * GPW, acc, col_active);
+      else
+        spmm_accumulate<D>(col, val, X + 4 * l, rowptr[row], rowptr[row + 1], wave * GPW + grp, kWavesPerBlock * GPW, acc);
 #pragma unroll
       for (int m = LPR; m < kWave; m <<= 1) {
         acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
@@ -112,10 +128,14 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int32_t* __restr
   } else {
     const int nwaves = (gridDim.x - kSpmmHeavyBlocks) * kWavesPerBlock;
     for (int row = (blockIdx.x - kSpmmHeavyBlocks) * kWavesPerBlock + wave; row < n; row += nwaves) {
+      if (SUB && row_active && !row_active[row]) continue;          // wave-uniform: one byte, then the next row
       const int lo = rowptr[row], hi = rowptr[row + 1];
       if (hi - lo > heavy_t) continue;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      spmm_accumulate<D>(col, val, X + 4 * l, lo, hi, grp, GPW, acc);
+      if (SUB && col_active)
+        spmm_accumulate<D, true>(col, val, X + 4 * l, lo, hi, grp, GPW, acc, col_active);
+      else
+        spmm_accumulate<D>(col, val, X + 4 * l, lo, hi, grp, GPW, acc);
 #pragma unroll
       for (int m = LPR; m < kWave; m <<= 1) {
         acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
@@ -317,12 +337,40 @@ struct DenseTile {
   static constexpr int RPI = kWave / LPR;    // rows per load instruction
 };
 
-template <int D>
+// SUB (row-list form, yr_ngcf_dense_*_rows): the tiles are made of the rows `rows[0 .. *count)` (node numbers, any
+// order; the count lives on the device, so the host never waits for it) instead of rows 0 .. n-1, and the
+// workgroups stride over the tiles.  Every output row depends on its own input row only and takes the same
+// instruction sequence in both forms: bit-identical results on the listed rows.
+// Full form: one tile per workgroup.  Row-list form: the workgroups stride over the tiles; the weight pointers go
+// through an empty asm per tile so that the compiler does not hoist the (tile-invariant) 2 D^2 weight loads out of
+// the loop into registers — that took ngcf_dense_fwd_kernel<64> from 112 to 252 VGPRs (one wave per SIMD).
+#define YR_DENSE_TILES(tile, WA, WB)                                                        \
+  if (!SUB) {                                                                               \
+    if ((int64_t)blockIdx.x * 32 < cnt) tile((int64_t)blockIdx.x * 32, WA, WB);             \
+  } else {                                                                                  \
+    _Pragma("nounroll") for (int64_t row0 = (int64_t)blockIdx.x * 32; row0 < cnt;           \
+                             row0 += (int64_t)gridDim.x * 32) {                             \
+      const float* wa = WA;                                                                 \
+      const float* wb = WB;                                                                 \
+      asm volatile("" : "+s"(wa), "+s"(wb));                                                \
+      tile(row0, wa, wb);                                                                   \
+      __syncthreads(); /* the staged tile is free for the next one */                       \
+    }                                                                                       \
+  }
+
+template <int D, bool SUB>
+__device__ __forceinline__ int64_t dense_row(const int32_t* __restrict__ rows, int64_t idx, int cnt) {
+  return idx < cnt ? (SUB ? (int64_t)rows[idx] : idx) : -1;
+}
+
+template <int D, bool SUB = false>
 __global__ __launch_bounds__(kWave) void ngcf_dense_fwd_kernel(const float* __restrict__ E,
                                                                const float* __restrict__ Z,
                                                                const float* __restrict__ W1,
                                                                const float* __restrict__ W2, int n,
-                                                               float* __restrict__ Eout) {
+                                                               float* __restrict__ Eout,
+                                                               const int32_t* __restrict__ rows = nullptr,
+                                                               const int32_t* __restrict__ count = nullptr) {
   using T = DenseTile<D>;
   constexpr int HALF = D / 2;
   constexpr int CT = (D + 31) / 32;          // 32-column output tiles
@@ -330,16 +378,19 @@ __global__ __launch_bounds__(kWave) void ngcf_dense_fwd_kernel(const float* __re
   __shared__ float s_h[T::FLOATS];
   const int lane = threadIdx.x;
   const int i = lane & 31, h = lane >> 5;
-  const int64_t row0 = (int64_t)blockIdx.x * 32;
+  const int cnt = SUB ? *count : n;
+  auto tile = [&](const int64_t row0, const float* __restrict__ W1, const float* __restrict__ W2) {
+  const int64_t out_row = dense_row<D, SUB>(rows, row0 + i, cnt);
   {
     const int c4 = (lane % T::LPR) * 4;
 #pragma unroll
     for (int rr = 0; rr < 32 / T::RPI; ++rr) {
       const int r = rr * T::RPI + lane / T::LPR;
       float4 e = make_float4(0.f, 0.f, 0.f, 0.f), z = e;
-      if (row0 + r < n) {
-        e = ngcf_ld4(E + (row0 + r) * D + c4);
-        z = ngcf_ld4(Z + (row0 + r) * D + c4);
+      const int64_t pr = dense_row<D, SUB>(rows, row0 + r, cnt);
+      if (pr >= 0) {
+        e = ngcf_ld4(E + pr * D + c4);
+        z = ngcf_ld4(Z + pr * D + c4);
       }
       *reinterpret_cast<float4*>(s_a + r * T::PITCH + c4) = make_float4(z.x + e.x, z.y + e.y, z.z + e.z, z.w + e.w);
       *reinterpret_cast<float4*>(s_h + r * T::PITCH + c4) = make_float4(e.x * z.x, e.y * z.y, e.z * z.z, e.w * z.w);
@@ -375,7 +426,7 @@ __global__ __launch_bounds__(kWave) void ngcf_dense_fwd_kernel(const float* __re
     for (int s = 0; s < HALF; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], aH[s], acc, 0, 0, 0);
     // the WEIGHTS are the A operand: lane (i, h) holds, for node row0 + i, the output columns
     // 32 t + 8 g + 4 h + {0..3} in registers 4 g .. 4 g + 3 — four consecutive floats, one 16-byte store each
-    if (row0 + i < n) {
+    if (out_row >= 0) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int c = t * 32 + 8 * g + 4 * h;
@@ -385,36 +436,42 @@ __global__ __launch_bounds__(kWave) void ngcf_dense_fwd_kernel(const float* __re
           o.y = acc[4 * g + 1] > 0.0f ? acc[4 * g + 1] : kSlope * acc[4 * g + 1];
           o.z = acc[4 * g + 2] > 0.0f ? acc[4 * g + 2] : kSlope * acc[4 * g + 2];
           o.w = acc[4 * g + 3] > 0.0f ? acc[4 * g + 3] : kSlope * acc[4 * g + 3];
-          *reinterpret_cast<float4*>(Eout + (row0 + i) * D + c) = o;
+          *reinterpret_cast<float4*>(Eout + out_row * D + c) = o;
         }
       }
     }
   }
+  };
+  YR_DENSE_TILES(tile, W1, W2)
 }
 
 // dP = dEout * lrelu'(Eout);  [dA | dH] = dP . [W1 | W2]  (W1T/W2T = transposed weights, [in, out]);
 // dZ = dA + dH * E;  dE += dA + dH * Z
-template <int D>
+template <int D, bool SUB = false>
 __global__ __launch_bounds__(kWave) void ngcf_dense_bwd_data_kernel(
     const float* __restrict__ dEout, const float* __restrict__ Eout, const float* __restrict__ E,
     const float* __restrict__ Z, const float* __restrict__ W1T, const float* __restrict__ W2T, int n,
-    float* __restrict__ dZ, float* __restrict__ dE) {
+    float* __restrict__ dZ, float* __restrict__ dE, const int32_t* __restrict__ rows = nullptr,
+    const int32_t* __restrict__ count = nullptr) {
   using T = DenseTile<D>;
   constexpr int HALF = D / 2;
   constexpr int CT = (D + 31) / 32;
   __shared__ float s_p[T::FLOATS];
   const int lane = threadIdx.x;
   const int i = lane & 31, h = lane >> 5;
-  const int64_t row0 = (int64_t)blockIdx.x * 32;
+  const int cnt = SUB ? *count : n;
+  auto tile = [&](const int64_t row0, const float* __restrict__ W1T, const float* __restrict__ W2T) {
+  const int64_t out_row = dense_row<D, SUB>(rows, row0 + i, cnt);
   {
     const int c4 = (lane % T::LPR) * 4;
 #pragma unroll
     for (int rr = 0; rr < 32 / T::RPI; ++rr) {
       const int r = rr * T::RPI + lane / T::LPR;
       float4 g = make_float4(0.f, 0.f, 0.f, 0.f), o = g;
-      if (row0 + r < n) {
-        g = ngcf_ld4(dEout + (row0 + r) * D + c4);
-        o = ngcf_ld4(Eout + (row0 + r) * D + c4);
+      const int64_t pr = dense_row<D, SUB>(rows, row0 + r, cnt);
+      if (pr >= 0) {
+        g = ngcf_ld4(dEout + pr * D + c4);
+        o = ngcf_ld4(Eout + pr * D + c4);
       }
       *reinterpret_cast<float4*>(s_p + r * T::PITCH + c4) =
           make_float4(o.x > 0.0f ? g.x : kSlope * g.x, o.y > 0.0f ? g.y : kSlope * g.y,
@@ -449,12 +506,12 @@ __global__ __launch_bounds__(kWave) void ngcf_dense_bwd_data_kernel(
     for (int s = 0; s < HALF; ++s) accH = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], a[s], accH, 0, 0, 0);
     // weights as the A operand (see the forward kernel): lane (i, h) holds columns 32 t + 8 g + 4 h + {0..3} of
     // node row0 + i in registers 4 g .. 4 g + 3 — 16-byte loads and stores instead of 4-byte ones
-    if (row0 + i < n) {
+    if (out_row >= 0) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int cc = t * 32 + 8 * g + 4 * h;
         if (cc < D) {
-          const int64_t o = (row0 + i) * D + cc;
+          const int64_t o = out_row * D + cc;
           const float4 e = ngcf_ld4(E + o), z = ngcf_ld4(Z + o);
           float4 de = *reinterpret_cast<const float4*>(dE + o);
           float4 dz;
@@ -472,6 +529,8 @@ __global__ __launch_bounds__(kWave) void ngcf_dense_bwd_data_kernel(
       }
     }
   }
+  };
+  YR_DENSE_TILES(tile, W1T, W2T)
 }
 
 // dW1[j, c] += sum_r dP[r, j] (Z+E)[r, c];  dW2[j, c] += sum_r dP[r, j] (E*Z)[r, c]
@@ -482,10 +541,12 @@ template <int D>
 struct WChunk {
   static constexpr int ROWS = 4096 / D;      // rows per workgroup: 3 staged tiles stay under 64 KiB of LDS
 };
-template <int D>
+template <int D, bool SUB = false>
 __global__ __launch_bounds__(kBlock) void ngcf_dense_bwd_weight_kernel(
     const float* __restrict__ dEout, const float* __restrict__ Eout, const float* __restrict__ E,
-    const float* __restrict__ Z, int n, float* __restrict__ dW1, float* __restrict__ dW2) {
+    const float* __restrict__ Z, int n_all, float* __restrict__ dW1, float* __restrict__ dW2,
+    const int32_t* __restrict__ rows = nullptr, const int32_t* __restrict__ count = nullptr) {
+  const int n = SUB ? *count : n_all;         // rows to sum over: the list's length in the row-list form
   // pitch D: an MFMA operand read is 32 consecutive floats of one staged row per half-wave, which is
   // conflict-free at any pitch, and a multiple of 4 keeps the staging stores 16 bytes wide
   constexpr int PITCH = D;
@@ -493,6 +554,7 @@ __global__ __launch_bounds__(kBlock) void ngcf_dense_bwd_weight_kernel(
   constexpr int RT = (D + 31) / 32;          // tiles along j (rows of dW) and along c (per matrix)
   constexpr int NT = RT * RT * 2;            // output tiles: RT x RT for dW1, same for dW2
   constexpr int NV = kWRows * D / 4 / kBlock;   // float4 per thread per operand and chunk (= 4)
+  if (SUB && (int64_t)blockIdx.x * kWRows >= n) return;   // row-list form: the grid is sized for an upper bound
   __shared__ __attribute__((aligned(16))) float s_dp[kWRows * PITCH];
   __shared__ __attribute__((aligned(16))) float s_a[kWRows * PITCH];
   __shared__ __attribute__((aligned(16))) float s_h[kWRows * PITCH];
@@ -512,7 +574,7 @@ __global__ __launch_bounds__(kBlock) void ngcf_dense_bwd_weight_kernel(
       const int c4 = (q % (D / 4)) * 4;
       pg[v] = po[v] = pe[v] = pz[v] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r < n) {
-        const int64_t o = r * D + c4;
+        const int64_t o = (SUB ? (int64_t)rows[r] : r) * D + c4;
         pg[v] = ngcf_ld4(dEout + o); po[v] = ngcf_ld4(Eout + o); pe[v] = ngcf_ld4(E + o); pz[v] = ngcf_ld4(Z + o);
       }
     }
@@ -576,6 +638,54 @@ __global__ __launch_bounds__(kBlock) void ngcf_dense_bwd_weight_kernel(
   }
 }
 
+// --------------------------------------------------------------------------- frontier of a batch
+// The scores of a batch read layer K at the rows R_K = {u} + {U + p} + {U + n} only (models/ngcf.py:37-39), layer
+// K-1 is then needed at R_K and its neighbours, and so on: S_K = R_K, S_{k-1} = S_k + N(S_k).  Flags are one byte
+// per node; the row list of a flag set is compacted with one counter atomic per wave (any order: every row is
+// computed on its own), its length stays on the device.
+__global__ __launch_bounds__(kBlock) void ngcf_frontier_mark_kernel(const int64_t* __restrict__ user,
+                                                                    const int64_t* __restrict__ pos,
+                                                                    const int64_t* __restrict__ neg, int64_t B,
+                                                                    int64_t num_users, int64_t num_items,
+                                                                    uint8_t* __restrict__ flags) {
+  for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += (int64_t)gridDim.x * kBlock) {
+    const int64_t u = user[b], p = pos[b], q = neg ? neg[b] : 0;
+    if (u >= 0 && u < num_users) flags[u] = 1;            // out-of-range ids: the score kernel raises the flag
+    if (p >= 0 && p < num_items) flags[num_users + p] = 1;
+    if (neg && q >= 0 && q < num_items) flags[num_users + q] = 1;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void ngcf_frontier_expand_kernel(const int32_t* __restrict__ rowptr,
+                                                                      const int32_t* __restrict__ col, int n,
+                                                                      const uint8_t* __restrict__ in,
+                                                                      uint8_t* __restrict__ out) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int nwaves = gridDim.x * kWavesPerBlock;
+  for (int row = blockIdx.x * kWavesPerBlock + wave; row < n; row += nwaves) {
+    if (!in[row]) continue;
+    if (lane == 0) out[row] = 1;
+    const int lo = rowptr[row], hi = rowptr[row + 1];
+    for (int idx = lo + lane; idx < hi; idx += kWave) out[col[idx]] = 1;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void ngcf_frontier_list_kernel(const uint8_t* __restrict__ flags, int n,
+                                                                    int32_t* __restrict__ rows,
+                                                                    int32_t* __restrict__ count) {
+  const int lane = threadIdx.x & (kWave - 1);
+  for (int base = (blockIdx.x * kBlock + threadIdx.x) - lane; base < n; base += gridDim.x * kBlock) {
+    const int row = base + lane;
+    const bool on = row < n && flags[row];
+    const unsigned long long m = __ballot(on);
+    if (m == 0) continue;
+    int at = 0;
+    if (lane == 0) at = atomicAdd(count, __popcll(m));
+    at = __shfl(at, 0, kWave);
+    if (on) rows[at + __popcll(m & ((1ull << lane) - 1ull))] = row;
+  }
+}
+
 }  // namespace yr
 
 using namespace yr;
@@ -608,6 +718,69 @@ extern "C" int yr_spmm_csr(const int32_t* rowptr, const int32_t* col, const floa
     YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_csr_kernel<kD, false>), dim3(grid), dim3(kBlock), 0, s, rowptr, col,
                                            val, X, Y, (int)n, heavy_rows, (int)n_heavy, heavy_threshold));
   }
+  return launch_status();
+}
+
+extern "C" int yr_spmm_csr_subset(const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
+                                  float* Y, int64_t n, int D, int accumulate, const int32_t* heavy_rows,
+                                  int64_t n_heavy, int heavy_threshold, const uint8_t* row_active,
+                                  const uint8_t* col_active, void* stream) {
+  if (n < 0 || n > 0x7fffffff || n_heavy < 0 || n_heavy > n) return YR_ERR_BADARG;
+  if (n == 0) return 0;
+  if (!rowptr || !X || !Y || X == Y) return YR_ERR_BADARG;
+  if (n_heavy > 0 && !heavy_rows) return YR_ERR_BADARG;
+  if (heavy_threshold <= 0 || n_heavy == 0) heavy_threshold = n_heavy > 0 ? 256 : 0x7fffffff;
+  int light = (int)((n + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (light > 65536) light = 65536;
+  const int grid = kSpmmHeavyBlocks + light;
+  hipStream_t s = (hipStream_t)stream;
+  if (accumulate) {
+    YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_csr_kernel<kD, true, true>), dim3(grid), dim3(kBlock), 0, s, rowptr,
+                                           col, val, X, Y, (int)n, heavy_rows, (int)n_heavy, heavy_threshold,
+                                           row_active, col_active));
+  } else {
+    YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_csr_kernel<kD, false, true>), dim3(grid), dim3(kBlock), 0, s, rowptr,
+                                           col, val, X, Y, (int)n, heavy_rows, (int)n_heavy, heavy_threshold,
+                                           row_active, col_active));
+  }
+  return launch_status();
+}
+
+extern "C" int yr_ngcf_frontier_mark(const int64_t* user, const int64_t* pos, const int64_t* neg, int64_t B,
+                                     int64_t num_users, int64_t num_items, uint8_t* flags, void* stream) {
+  if (B < 0 || num_users <= 0 || num_items <= 0 || !flags) return YR_ERR_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(flags, 0, (size_t)(num_users + num_items), s) != hipSuccess) return (int)hipGetLastError();
+  if (B == 0) return 0;
+  if (!user || !pos) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(ngcf_frontier_mark_kernel, dim3(grid_for(B, kBlock)), dim3(kBlock), 0, s, user, pos, neg, B,
+                     num_users, num_items, flags);
+  return launch_status();
+}
+
+extern "C" int yr_ngcf_frontier_expand(const int32_t* rowptr, const int32_t* col, int64_t n, const uint8_t* flags_in,
+                                       uint8_t* flags_out, void* stream) {
+  if (n < 0 || n > 0x7fffffff) return YR_ERR_BADARG;
+  if (n == 0) return 0;
+  if (!rowptr || !col || !flags_in || !flags_out || flags_in == flags_out) return YR_ERR_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(flags_out, 0, (size_t)n, s) != hipSuccess) return (int)hipGetLastError();
+  int grid = (int)((n + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (grid > 65536) grid = 65536;
+  hipLaunchKernelGGL(ngcf_frontier_expand_kernel, dim3(grid), dim3(kBlock), 0, s, rowptr, col, (int)n, flags_in,
+                     flags_out);
+  return launch_status();
+}
+
+extern "C" int yr_ngcf_frontier_list(const uint8_t* flags, int64_t n, int32_t* rows, int32_t* count, void* stream) {
+  if (n < 0 || n > 0x7fffffff) return YR_ERR_BADARG;
+  if (!count) return YR_ERR_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(count, 0, sizeof(int32_t), s) != hipSuccess) return (int)hipGetLastError();
+  if (n == 0) return 0;
+  if (!flags || !rows) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(ngcf_frontier_list_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, flags, (int)n, rows,
+                     count);
   return launch_status();
 }
 
@@ -724,6 +897,52 @@ extern "C" int yr_ngcf_dense_bwd_weight(const float* dEout, const float* Eout, c
     const int64_t per_block = (chunks + 511) / 512;            // <= 512 workgroups, equal shares
     hipLaunchKernelGGL((ngcf_dense_bwd_weight_kernel<kD>), dim3((unsigned)((chunks + per_block - 1) / per_block)),
                        dim3(kBlock), 0, (hipStream_t)stream, dEout, Eout, E, Z, (int)n, dW1, dW2);
+  });
+  return launch_status();
+}
+
+// Row-list forms: the same kernels over the rows `rows[0 .. *count)`; `max_rows` (<= n) is the host's upper bound of
+// *count and only sizes the grid — the workgroups stride, so any count up to n is covered.
+static int rows_args_ok(int64_t n, const int32_t* rows, const int32_t* count, int64_t max_rows) {
+  return n >= 0 && n <= 0x7fffffff && rows && count && max_rows >= 0 && max_rows <= n;
+}
+
+extern "C" int yr_ngcf_dense_fwd_rows(const float* E, const float* Z, const float* W1, const float* W2, int64_t n,
+                                      int D, float* Eout, const int32_t* rows, const int32_t* count,
+                                      int64_t max_rows, void* stream) {
+  if (!rows_args_ok(n, rows, count, max_rows)) return YR_ERR_BADARG;
+  if (n == 0 || max_rows == 0) return 0;
+  if (!E || !Z || !W1 || !W2 || !Eout) return YR_ERR_BADARG;
+  const int grid = (int)((max_rows + 31) / 32);
+  YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((ngcf_dense_fwd_kernel<kD, true>), dim3(grid), dim3(kWave), 0,
+                                         (hipStream_t)stream, E, Z, W1, W2, (int)n, Eout, rows, count));
+  return launch_status();
+}
+
+extern "C" int yr_ngcf_dense_bwd_data_rows(const float* dEout, const float* Eout, const float* E, const float* Z,
+                                           const float* W1T, const float* W2T, int64_t n, int D, float* dZ,
+                                           float* dE, const int32_t* rows, const int32_t* count, int64_t max_rows,
+                                           void* stream) {
+  if (!rows_args_ok(n, rows, count, max_rows)) return YR_ERR_BADARG;
+  if (n == 0 || max_rows == 0) return 0;
+  if (!dEout || !Eout || !E || !Z || !W1T || !W2T || !dZ || !dE) return YR_ERR_BADARG;
+  const int grid = (int)((max_rows + 31) / 32);
+  YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((ngcf_dense_bwd_data_kernel<kD, true>), dim3(grid), dim3(kWave), 0,
+                                         (hipStream_t)stream, dEout, Eout, E, Z, W1T, W2T, (int)n, dZ, dE, rows, count));
+  return launch_status();
+}
+
+extern "C" int yr_ngcf_dense_bwd_weight_rows(const float* dEout, const float* Eout, const float* E, const float* Z,
+                                             int64_t n, int D, float* dW1, float* dW2, const int32_t* rows,
+                                             const int32_t* count, int64_t max_rows, void* stream) {
+  if (!rows_args_ok(n, rows, count, max_rows)) return YR_ERR_BADARG;
+  if (n == 0 || max_rows == 0) return 0;
+  if (!dEout || !Eout || !E || !Z || !dW1 || !dW2) return YR_ERR_BADARG;
+  YR_NGCF_DISPATCH(D, {
+    const int64_t chunks = (max_rows + WChunk<kD>::ROWS - 1) / WChunk<kD>::ROWS;
+    const int64_t per_block = (chunks + 511) / 512;
+    hipLaunchKernelGGL((ngcf_dense_bwd_weight_kernel<kD, true>), dim3((unsigned)((chunks + per_block - 1) / per_block)),
+                       dim3(kBlock), 0, (hipStream_t)stream, dEout, Eout, E, Z, (int)n, dW1, dW2, rows, count);
   });
   return launch_status();
 }

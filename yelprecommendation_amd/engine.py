@@ -254,6 +254,61 @@ def _ptr_array(tensors, what):
     return (ctypes.c_void_p * len(tensors))(*[_dev(t, torch.float32, what) for t in tensors])
 
 
+class NGCFRowSet:
+    """A set of graph nodes for the batch-aware propagation: ``flags`` uint8[N] (1 = member), ``rows`` int32[N]
+    of which the first ``count[0]`` entries list the members (count stays on the device), ``max_rows`` the
+    host's upper bound of the count (sizes grids only)."""
+    __slots__ = ("flags", "rows", "count", "max_rows")
+
+    def __init__(self, flags, max_rows):
+        lib = _lib.load()
+        n = flags.numel()
+        self.flags, self.max_rows = flags, int(min(max_rows, n))
+        self.rows = torch.empty(n, dtype=torch.int32, device=flags.device)
+        self.count = torch.empty(1, dtype=torch.int32, device=flags.device)
+        check(lib.yr_ngcf_frontier_list(_dev(flags, torch.uint8, "flags"), n, self.rows.data_ptr(),
+                                        self.count.data_ptr(), _stream()), "yr_ngcf_frontier_list")
+
+
+def ngcf_frontier_mark(num_users, num_items, user_id, pos_ids, neg_ids=None):
+    """uint8[num_users + num_items] flags of the rows a batch's scores read: user_id, num_users + pos_ids,
+    num_users + neg_ids (reference models/ngcf.py:31-32,37-39)."""
+    lib = _lib.load()
+    i64 = torch.int64
+    flags = torch.empty(num_users + num_items, dtype=torch.uint8, device=user_id.device)
+    check(lib.yr_ngcf_frontier_mark(_dev(user_id, i64, "user_id"), _dev(pos_ids, i64, "pos_ids"),
+                                    _dev(neg_ids, i64, "neg_ids") if neg_ids is not None else None, user_id.numel(),
+                                    num_users, num_items, flags.data_ptr(), _stream()), "yr_ngcf_frontier_mark")
+    return flags
+
+
+def ngcf_frontier_expand(graph, flags):
+    """flags of the given rows plus all their neighbours in the graph."""
+    lib = _lib.load()
+    out = torch.empty_like(flags)
+    check(lib.yr_ngcf_frontier_expand(_dev(graph.rowptr, torch.int32, "rowptr"), _dev(graph.col, torch.int32, "col"),
+                                      graph.n, _dev(flags, torch.uint8, "flags"), out.data_ptr(), _stream()),
+          "yr_ngcf_frontier_expand")
+    return out
+
+
+def spmm_csr_subset(graph, X, out, row_active=None, col_active=None, accumulate=False):
+    """:func:`spmm_csr` on the rows flagged in ``row_active`` (None: all) and, with ``col_active``, over the
+    flagged neighbours only; other rows of ``out`` are left as they are."""
+    lib = _lib.load()
+    n, d = X.shape
+    if n != graph.n or out.shape != X.shape:
+        raise EngineError(f"X / out must be [{graph.n}, D]")
+    u8 = torch.uint8
+    check(lib.yr_spmm_csr_subset(_dev(graph.rowptr, torch.int32, "rowptr"), _dev(graph.col, torch.int32, "col"),
+                                 _dev(graph.val, torch.float32, "val"), _dev(X, torch.float32, "X"),
+                                 _dev(out, torch.float32, "Y"), n, d, 1 if accumulate else 0,
+                                 _opt(graph.heavy_rows, torch.int32, "heavy_rows"), graph.n_heavy, graph.heavy_threshold,
+                                 _opt(row_active, u8, "row_active"), _opt(col_active, u8, "col_active"), _stream()),
+          "yr_spmm_csr_subset")
+    return out
+
+
 def ngcf_score(layers, num_users, user_id, pos_ids, neg_ids=None, err_flag=None):
     """Scores of the concatenated layer embeddings (reference models/ngcf.py:44-58): returns
     ``pos`` or ``(pos, neg)``, each the sum over layers of per-layer dot products."""
@@ -286,22 +341,29 @@ def ngcf_score_backward(layers, dlayers, num_users, user_id, pos_ids, neg_ids, g
                                 err_flag.data_ptr() if err_flag is not None else None, _stream()), "yr_ngcf_score_bwd")
 
 
-def ngcf_dense_fwd(E, Z, W1, W2, out=None):
-    """leaky_relu((Z + E) W1^T + (E * Z) W2^T)   (reference models/ngcf.py:64-72)."""
+def ngcf_dense_fwd(E, Z, W1, W2, out=None, rows=None):
+    """leaky_relu((Z + E) W1^T + (E * Z) W2^T)   (reference models/ngcf.py:64-72).  ``rows`` (NGCFRowSet): only
+    those rows are computed (and written)."""
     lib = _lib.load()
     n, d = E.shape
     if out is None:
         out = torch.empty_like(E)
     f32 = torch.float32
+    if rows is not None:
+        check(lib.yr_ngcf_dense_fwd_rows(_dev(E, f32, "E"), _dev(Z, f32, "Z"), _dev(W1, f32, "W1"), _dev(W2, f32, "W2"),
+                                         n, d, _dev(out, f32, "Eout"), rows.rows.data_ptr(), rows.count.data_ptr(),
+                                         rows.max_rows, _stream()), "yr_ngcf_dense_fwd_rows")
+        return out
     check(lib.yr_ngcf_dense_fwd(_dev(E, f32, "E"), _dev(Z, f32, "Z"), _dev(W1, f32, "W1"), _dev(W2, f32, "W2"),
                                 n, d, _dev(out, f32, "Eout"), _stream()), "yr_ngcf_dense_fwd")
     return out
 
 
-def ngcf_dense_bwd(dEout, Eout, E, Z, W1, W2, dE, dW1, dW2, dZ=None, W1T=None, W2T=None):
+def ngcf_dense_bwd(dEout, Eout, E, Z, W1, W2, dE, dW1, dW2, dZ=None, W1T=None, W2T=None, rows=None):
     """Backward of :func:`ngcf_dense_fwd`: dE += ..., dW1 += ..., dW2 += ..., returns dZ.
     ``W1T / W2T``: the transposed weights if the caller already has them (one batched transpose
-    for all layers instead of two small launches per layer)."""
+    for all layers instead of two small launches per layer).  ``rows`` (NGCFRowSet): the rows outside it have
+    dEout = 0 and are skipped (their dZ is not written)."""
     lib = _lib.load()
     n, d = E.shape
     f32 = torch.float32
@@ -309,6 +371,16 @@ def ngcf_dense_bwd(dEout, Eout, E, Z, W1, W2, dE, dW1, dW2, dZ=None, W1T=None, W
         dZ = torch.empty_like(E)
     if W1T is None:
         W1T, W2T = W1.t().contiguous(), W2.t().contiguous()  # [in, out] layout for the data-gradient GEMM
+    if rows is not None:
+        r, c, m = rows.rows.data_ptr(), rows.count.data_ptr(), rows.max_rows
+        check(lib.yr_ngcf_dense_bwd_weight_rows(_dev(dEout, f32, "dEout"), _dev(Eout, f32, "Eout"), _dev(E, f32, "E"),
+                                                _dev(Z, f32, "Z"), n, d, _dev(dW1, f32, "dW1"), _dev(dW2, f32, "dW2"),
+                                                r, c, m, _stream()), "yr_ngcf_dense_bwd_weight_rows")
+        check(lib.yr_ngcf_dense_bwd_data_rows(_dev(dEout, f32, "dEout"), _dev(Eout, f32, "Eout"), _dev(E, f32, "E"),
+                                              _dev(Z, f32, "Z"), _dev(W1T, f32, "W1T"), _dev(W2T, f32, "W2T"), n, d,
+                                              _dev(dZ, f32, "dZ"), _dev(dE, f32, "dE"), r, c, m, _stream()),
+              "yr_ngcf_dense_bwd_data_rows")
+        return dZ
     check(lib.yr_ngcf_dense_bwd_weight(_dev(dEout, f32, "dEout"), _dev(Eout, f32, "Eout"), _dev(E, f32, "E"),
                                        _dev(Z, f32, "Z"), n, d, _dev(dW1, f32, "dW1"), _dev(dW2, f32, "dW2"),
                                        _stream()), "yr_ngcf_dense_bwd_weight")

@@ -32,18 +32,32 @@ class _NGCFScores(torch.autograd.Function):
     gradients of the embedding table and every W1/W2."""
 
     @staticmethod
-    def forward(ctx, graph, num_users, user_id, pos_ids, neg_ids, err_flag, E0, *weights):
+    def forward(ctx, graph, num_users, subset_fraction, user_id, pos_ids, neg_ids, err_flag, E0, *weights):
         K = len(weights) // 2
         W1s, W2s = weights[:K], weights[K:]
         E0d = E0.detach()
-        layers, Zs = [E0d], []
-        for k in range(K):
-            Z = engine.spmm_csr(graph, layers[-1])
-            Zs.append(Z)
-            layers.append(engine.ngcf_dense_fwd(layers[-1], Z, W1s[k].detach(), W2s[k].detach()))
         user_id = user_id.contiguous()
         pos_ids = pos_ids.contiguous()
         neg_ids = None if neg_ids is None else neg_ids.contiguous()
+        # Batch-aware propagation: the scores read layer K at the batch's rows only (models/ngcf.py:37-39), layer
+        # k-1 is needed at those rows and their neighbours, ...: sets[k] is the NGCFRowSet layer k + 1 is computed
+        # on, or None for the whole graph.  Which layers are restricted is decided on the host from an ESTIMATE of
+        # the set sizes (rows x (1 + average degree) per hop, against subset_fraction x N) so that every rank /
+        # run takes the same launches without reading a size back; the kernels themselves take the exact sets.
+        sets = _subset_plan(graph, num_users, K, user_id, pos_ids, neg_ids, subset_fraction)
+        layers, Zs = [E0d], []
+        for k in range(K):
+            if sets[k] is None:
+                Z = engine.spmm_csr(graph, layers[-1])
+                out = engine.ngcf_dense_fwd(layers[-1], Z, W1s[k].detach(), W2s[k].detach())
+            else:
+                # rows outside the set stay unwritten: nothing downstream reads them (the next layer's set and
+                # its neighbours lie inside this one)
+                Z = engine.spmm_csr_subset(graph, layers[-1], torch.empty_like(E0d), row_active=sets[k].flags)
+                out = engine.ngcf_dense_fwd(layers[-1], Z, W1s[k].detach(), W2s[k].detach(), rows=sets[k])
+            Zs.append(Z)
+            layers.append(out)
+        ctx.sets = sets
         # users are rows [0, num_users), items rows [num_users, N) of every layer buffer
         res = engine.ngcf_score(layers, num_users, user_id, pos_ids, neg_ids, err_flag=err_flag)
         pos, neg = res if neg_ids is not None else (res, None)
@@ -78,10 +92,38 @@ class _NGCFScores(torch.autograd.Function):
         for k in range(K - 1, -1, -1):
             dW1s[k], dW2s[k] = dWstack[k], dWstack[K + k]
             # dlayers[k] += dA + dH * Z ; dZ = dA + dH * E ; then dlayers[k] += L^T dZ (L symmetric)
+            cur = ctx.sets[k]
             dZ = engine.ngcf_dense_bwd(dlayers[k + 1], layers[k + 1], layers[k], Zs[k], W1s[k], W2s[k],
-                                       dlayers[k], dW1s[k], dW2s[k], W1T=WT[k], W2T=WT[K + k])
-            engine.spmm_csr(graph, dZ, out=dlayers[k], accumulate=True)
-        return (None, None, None, None, None, None, dlayers[0], *dW1s, *dW2s)
+                                       dlayers[k], dW1s[k], dW2s[k], W1T=WT[k], W2T=WT[K + k], rows=cur)
+            if cur is None:
+                engine.spmm_csr(graph, dZ, out=dlayers[k], accumulate=True)
+            else:
+                # dZ is non-zero (and written) on this layer's set only: gather those neighbours, and only into
+                # the rows of the layer below's set (which holds every neighbour of this one)
+                below = ctx.sets[k - 1] if k > 0 else None
+                engine.spmm_csr_subset(graph, dZ, dlayers[k], row_active=None if below is None else below.flags,
+                                       col_active=cur.flags, accumulate=True)
+        return (None, None, None, None, None, None, None, dlayers[0], *dW1s, *dW2s)
+
+
+def _subset_plan(graph, num_users, K, user_id, pos_ids, neg_ids, fraction):
+    """[set of layer 1, ..., set of layer K] (engine.NGCFRowSet or None = all rows), see _NGCFScores.forward."""
+    sets = [None] * K
+    if K == 0 or not fraction or fraction <= 0:
+        return sets
+    n = graph.n
+    est = min(n, user_id.numel() * (2 if neg_ids is None else 3))
+    hop = 1.0 + graph.nnz / max(n, 1)
+    flags = None
+    for k in range(K - 1, -1, -1):
+        if est > fraction * n:
+            break
+        flags = (engine.ngcf_frontier_mark(num_users, n - num_users, user_id, pos_ids, neg_ids) if flags is None
+                 else engine.ngcf_frontier_expand(graph, flags))
+        # the last layer's set has at most `est` rows (exact bound); a deeper set's size is not known on the host
+        sets[k] = engine.NGCFRowSet(flags, est if k == K - 1 else n)
+        est = min(n, int(est * hop))
+    return sets
 
 
 def _iadd(acc, x):
@@ -158,15 +200,21 @@ class NGCF(BaseModel):
     def _weights(self):
         return [w.weight for w in self.W1] + [w.weight for w in self.W2]
 
+    def _subset_fraction(self):
+        """cfg.ngcf_subset_fraction (default 0.5): a layer is propagated on the rows the batch needs when their
+        estimated number is below this fraction of the graph; 0 = always the whole graph (the reference's shape)."""
+        get = getattr(self.cfg, "get", None)
+        return float(get("ngcf_subset_fraction", 0.5)) if get else 0.5
+
     def bpr_forward(self, user_id, pos_item_ids, neg_item_ids, laplacian_matrix):
         # reference models/ngcf.py:30-45
-        return _NGCFScores.apply(self.graph(laplacian_matrix), self.num_users, user_id, pos_item_ids,
-                                 neg_item_ids, self._flag(), self.embedding.weight, *self._weights())
+        return _NGCFScores.apply(self.graph(laplacian_matrix), self.num_users, self._subset_fraction(), user_id,
+                                 pos_item_ids, neg_item_ids, self._flag(), self.embedding.weight, *self._weights())
 
     def forward(self, user_id, item_id, laplacian_matrix):
         # reference models/ngcf.py:47-58
-        return _NGCFScores.apply(self.graph(laplacian_matrix), self.num_users, user_id, item_id, None,
-                                 self._flag(), self.embedding.weight, *self._weights())
+        return _NGCFScores.apply(self.graph(laplacian_matrix), self.num_users, self._subset_fraction(), user_id,
+                                 item_id, None, self._flag(), self.embedding.weight, *self._weights())
 
     def embedding_propagation(self, last_embed, w1, w2, laplacian_matrix):
         # reference models/ngcf.py:60-72
