@@ -279,27 +279,46 @@ int yr_ngcf_dense_bwd_weight(const float *dEout, const float *Eout, const float 
  * S_{k-1} = S_k + neighbours(S_k), layer k is needed on S_k alone; these entry points compute exactly that and
  * give, on the rows they compute, bit-identical results to the full-graph entry points above.
  *
- * yr_ngcf_frontier_mark: flags[0 .. num_users + num_items) = 0, then 1 at user[b], num_users + pos[b] and (neg may
- *   be NULL) num_users + neg[b] for every b < B; out-of-range ids are skipped (yr_ngcf_score_fwd reports them).
- * yr_ngcf_frontier_expand: flags_out = flags_in + neighbours (rows of the CSR) of every flagged row.
- * yr_ngcf_frontier_list: rows[0 .. *count) = the flagged rows (in no particular order), *count on the DEVICE (the
- *   host never waits for it); rows must hold n entries.
- * yr_spmm_csr_subset: yr_spmm_csr restricted to the rows with row_active[row] != 0 (other rows of Y untouched;
- *   NULL = all rows) and, with col_active, to the neighbours with col_active[col] != 0 — the backward product
- *   dE += L dZ where dZ is non-zero on a known row set only.
+ * A row set is `flags` (int32[n], 1 = member), `rows` (int32[n]: the members in rows[0 .. *count), in no particular
+ *   order) and `count` (int32 on the DEVICE: the host never waits for it).
+ * yr_ngcf_frontier_mark: the set {user[b], num_users + pos[b], num_users + neg[b] : b < B} (neg may be NULL);
+ *   out-of-range ids are skipped (yr_ngcf_score_fwd reports them).  clear != 0: flags and *count are zeroed first;
+ *   clear = 0: the caller has zeroed them (or extends an existing set).
+ * yr_ngcf_frontier_expand: the set (flags, rows, count) += the rows rows_in[0 .. *count_in) and all their
+ *   neighbours in the CSR; max_rows_in (<= n) = the host's upper bound of *count_in (sizes the grid).
+ * yr_spmm_csr_subset: yr_spmm_csr restricted to the rows with row_active[row] != 0 (int32 flags; other rows of Y
+ *   untouched; NULL = all rows) and, with col_active, to the neighbours with col_active[col] != 0.  row_list /
+ *   row_count / max_rows (optional, with row_active): the same set as a list — the rows with at most
+ *   heavy_threshold non-zeros are then taken from the list (a set of a few rows costs a few waves).
  * yr_ngcf_dense_{fwd,bwd_data,bwd_weight}_rows: the dense part of a layer over the rows rows[0 .. *count) instead
  *   of 0 .. n-1; max_rows (<= n) is the host's upper bound of *count and only sizes the grid (the workgroups
  *   stride over the list, so any count up to n is covered).
  * ------------------------------------------------------------------------- */
 int yr_ngcf_frontier_mark(const int64_t *user, const int64_t *pos, const int64_t *neg, int64_t B,
-                          int64_t num_users, int64_t num_items, uint8_t *flags, void *stream);
+                          int64_t num_users, int64_t num_items,
+                          int32_t *flags, int32_t *rows, int32_t *count, int clear, void *stream);
 int yr_ngcf_frontier_expand(const int32_t *rowptr, const int32_t *col, int64_t n,
-                            const uint8_t *flags_in, uint8_t *flags_out, void *stream);
-int yr_ngcf_frontier_list(const uint8_t *flags, int64_t n, int32_t *rows, int32_t *count, void *stream);
+                            const int32_t *rows_in, const int32_t *count_in, int64_t max_rows_in,
+                            int32_t *flags, int32_t *rows, int32_t *count, int clear, void *stream);
 int yr_spmm_csr_subset(const int32_t *rowptr, const int32_t *col, const float *val,
                        const float *X, float *Y, int64_t n, int D, int accumulate,
                        const int32_t *heavy_rows, int64_t n_heavy, int heavy_threshold,
-                       const uint8_t *row_active, const uint8_t *col_active, void *stream);
+                       const int32_t *row_active, const int32_t *col_active,
+                       const int32_t *row_list, const int32_t *row_count, int64_t max_rows, void *stream);
+/* yr_spmm_csr_clustered: yr_spmm_csr_subset with the rows visited in a clustered order — row_perm: int32[8 * chunk],
+ * chunk x (x = 0..7) lists the rows of graph cluster x, padded with -1; every row exactly once overall.  The
+ * workgroups the dispatcher places on XCD x (blockIdx % 8 == x) walk chunk x, so the neighbour rows that the rows
+ * of one cluster share stay in that XCD's L2.  Same results as yr_spmm_csr for any row_perm / placement. */
+int yr_spmm_csr_clustered(const int32_t *rowptr, const int32_t *col, const float *val,
+                          const float *X, float *Y, int64_t n, int D, int accumulate,
+                          const int32_t *heavy_rows, int64_t n_heavy, int heavy_threshold,
+                          const int32_t *row_perm, int64_t chunk, const int32_t *row_active, void *stream);
+/* yr_spmm_csr_push_rows: Y[j] += sum over the listed rows r of L[r, j] * X[r] — for a symmetric L the product
+ * Y += L X restricted to the columns rows[0 .. *count), as a scatter from those rows (float atomics); the cost is
+ * the list's non-zeros, not the graph's.  The backward product of a layer whose dZ lives on a few rows. */
+int yr_spmm_csr_push_rows(const int32_t *rowptr, const int32_t *col, const float *val,
+                          const float *X, float *Y, int64_t n, int D,
+                          const int32_t *rows, const int32_t *count, int64_t max_rows, void *stream);
 int yr_ngcf_dense_fwd_rows(const float *E, const float *Z, const float *W1, const float *W2,
                            int64_t n, int D, float *Eout,
                            const int32_t *rows, const int32_t *count, int64_t max_rows, void *stream);
@@ -309,6 +328,33 @@ int yr_ngcf_dense_bwd_data_rows(const float *dEout, const float *Eout, const flo
 int yr_ngcf_dense_bwd_weight_rows(const float *dEout, const float *Eout, const float *E, const float *Z,
                                   int64_t n, int D, float *dW1, float *dW2,
                                   const int32_t *rows, const int32_t *count, int64_t max_rows, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * yr_ngcf_bpr_step: ONE NGCF training step, every launch issued from C (ABI v28) — replaces, per batch,
+ *   pos, neg = model.bpr_forward(u, p, n, L); optimizer.zero_grad(); loss = BPRLoss(pos, neg); loss.backward();
+ *   optimizer.step(); train_loss += loss.item()              (reference trainers/ngcf_trainer.py:104-116,
+ *   models/ngcf.py:30-72, loss.py:25-27, trainers/base_trainer.py:34-38 with Adam / AdamW)
+ * with the kernels declared above (the autograd route issues the same ones from Python, ~0.55 ms of host time per
+ * step; this entry point costs the host ~0.1 ms).  Batch-aware: layer k + 1 runs on the rows the batch's scores
+ * need when their estimated number (3B, x (1 + nnz / n) per hop down) is at most subset_fraction * n — a plan made
+ * from host-known numbers only; 0 = always the whole graph.
+ *   graph: CSR of the symmetric propagation matrix + heavy-row list as for yr_spmm_csr; users are nodes
+ *   0 .. num_users-1, items the rest.
+ *   params / exp_avg / exp_avg_sq: HOST arrays of 1 + 2K device pointers in the order
+ *   [embedding.weight [n, D], W1.0 .. W1.K-1, W2.0 .. W2.K-1 ([D, D] each, [out, in])] — updated in place.
+ *   step_size / bc2_sqrt as for yr_adam_dense.  loss_out[0] = the batch's mean loss, loss_accum[0] += it
+ *   (either may be NULL).  workspace: yr_ngcf_step_workspace_bytes(n, D, K, B) bytes, 256-byte aligned, contents
+ *   irrelevant on entry; a workspace sized for batch B serves every smaller batch.
+ * ------------------------------------------------------------------------- */
+int64_t yr_ngcf_step_workspace_bytes(int64_t n, int D, int K, int64_t B);
+int yr_ngcf_bpr_step(const int32_t *rowptr, const int32_t *col, const float *val, int64_t n, int64_t nnz,
+                     const int32_t *heavy_rows, int64_t n_heavy, int heavy_threshold, int64_t num_users,
+                     float *const *params, float *const *exp_avg, float *const *exp_avg_sq, int K, int D,
+                     const int64_t *user, const int64_t *pos, const int64_t *neg, int64_t B,
+                     double lr, double step_size, double bc2_sqrt, double beta1, double beta2, double eps,
+                     double weight_decay, int mode, double subset_fraction,
+                     void *workspace, int64_t workspace_bytes, float *loss_out, double *loss_accum,
+                     int32_t *err_flag, void *stream);
 
 /* ---------------------------------------------------------------------------
  * CDAE                        (reference models/cdae.py:46-52, loss.py:12-16 and their autograd)

@@ -1,5 +1,5 @@
 """Full-size NGCF train step (K = 3, Yelp2018 shape): wall time per step for a batch size and a subset fraction.
-usage: python scratch/ngcf_step.py <batch> <fraction> [steps]   (under rocprofv3 --kernel-trace --stats for kernel sums)"""
+usage: python scratch/ngcf_step.py <batch> <fraction> [steps] [fused|autograd]   (under rocprofv3 --kernel-trace --stats for kernel sums)"""
 import sys, time
 import torch
 sys.path.insert(0, ".")
@@ -12,6 +12,7 @@ from yelprecommendation_amd.utils import make_config
 
 B, frac = int(sys.argv[1]), float(sys.argv[2])
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+route = sys.argv[4] if len(sys.argv) > 4 else "fused"
 dev = torch.device("cuda", 0)
 u, i = make_interactions_torch(NU, NI, 47.0, seed=1234, device=dev)
 r = torch.randint(1, 6, u.shape, device=dev)
@@ -23,7 +24,13 @@ pick = torch.randint(0, u.numel(), (B,), device=dev)
 bu, bp, bn = u[pick].contiguous(), i[pick].contiguous(), torch.randint(0, NI, (B,), device=dev)
 
 
+from yelprecommendation_amd.ngcf_step import NGCFStep
+fused = NGCFStep(model, opt, graph, frac) if route == "fused" else None
+
+
 def step():
+    if fused is not None:
+        return fused.step(bu, bp, bn)
     pos, neg = model.bpr_forward(bu, bp, bn, graph)
     opt.zero_grad(); lossf(pos, neg).backward(); opt.step()
 
@@ -40,4 +47,4 @@ t = (time.perf_counter() - t0) / steps
 from yelprecommendation_amd.models import ngcf as m
 sets = m._subset_plan(graph, NU, 3, bu, bp, bn, frac)
 sizes = [None if s is None else int(s.count.item()) for s in sets]
-print(f"B={B} fraction={frac}: {t*1e3:.4f} ms per step (host enqueue {t_host*1e3:.4f} ms), set sizes per layer {sizes} of {graph.n}")
+print(f"B={B} fraction={frac} {route}: {t*1e3:.4f} ms per step (host enqueue {t_host*1e3:.4f} ms), set sizes per layer {sizes} of {graph.n}")

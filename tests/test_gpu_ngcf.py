@@ -155,11 +155,13 @@ def test_seeded_init_matches_reference(g, tmp_path, device):
         np.testing.assert_array_equal(prm.detach().cpu().numpy(), g[f"init__{name.replace('.', '__')}"])
 
 
-def test_trainer_run_matches_reference(g, tmp_path, device):
+@pytest.mark.parametrize("fused", [True, False])
+def test_trainer_run_matches_reference(g, tmp_path, device, fused):
     """Replay the reference's recorded batches through NGCFTrainer: per-epoch losses, final parameters
-    and the 100-sampled-user metrics (same NumPy RNG positions) must match."""
+    and the 100-sampled-user metrics (same NumPy RNG positions) must match — with the whole batch step as one
+    engine call (ngcf_step.NGCFStep, the default) and through the launch-by-launch autograd route."""
     from yelprecommendation_amd.trainers import NGCFTrainer
-    cfg = _cfg(g, tmp_path)
+    cfg = _cfg(g, tmp_path, fused_step=fused)
     t = NGCFTrainer(cfg, int(g["num_items"]), int(g["num_users"]), _lap_torch(g))
     _load_init(t.model, g)
     users = g["valid_eval_users"]
@@ -336,25 +338,31 @@ def test_frontier_and_subset_kernels(device):
     t = lambda a: torch.from_numpy(a).to(device)
     bu, bp, bn = rs.randint(0, nu, 40), rs.randint(0, ni, 40), rs.randint(0, ni, 40)
     bp[:3] = (0, 1, 2)                                              # the heavy rows are in the batch
-    want0 = np.zeros(n, np.uint8)
+    want0 = np.zeros(n, np.int32)
     want0[bu] = 1; want0[nu + bp] = 1; want0[nu + bn] = 1
-    f0 = engine.ngcf_frontier_mark(nu, ni, t(bu), t(bp), t(bn))
+    s0 = engine.ngcf_frontier_mark(nu, ni, t(bu), t(bp), t(bn))
+    f0 = s0.flags
     np.testing.assert_array_equal(f0.cpu().numpy(), want0)
-    only_pos = engine.ngcf_frontier_mark(nu, ni, t(bu), t(bp), None).cpu().numpy()
-    assert only_pos.sum() == len(set(bu.tolist())) + len(set(bp.tolist()))
-    adj = (abs(L) > 0).astype(np.int32)
-    want1 = ((adj @ want0.astype(np.int32) > 0) | (want0 > 0)).astype(np.uint8)
-    f1 = engine.ngcf_frontier_expand(graph, f0)
-    np.testing.assert_array_equal(f1.cpu().numpy(), want1)
-    s0 = engine.NGCFRowSet(f0, 3 * 40)
     cnt = int(s0.count.item())
-    assert cnt == int(want0.sum()) and sorted(s0.rows[:cnt].cpu().tolist()) == np.flatnonzero(want0).tolist()
+    assert s0.max_rows == 120 and cnt == int(want0.sum())
+    assert sorted(s0.rows[:cnt].cpu().tolist()) == np.flatnonzero(want0).tolist()      # every member exactly once
+    only_pos = engine.ngcf_frontier_mark(nu, ni, t(bu), t(bp), None)
+    assert int(only_pos.count.item()) == int(only_pos.flags.sum()) == len(set(bu.tolist())) + len(set(bp.tolist()))
+    adj = (abs(L) > 0).astype(np.int32)
+    want1 = ((adj @ want0 > 0) | (want0 > 0)).astype(np.int32)
+    s1 = engine.ngcf_frontier_expand(graph, s0)
+    f1 = s1.flags
+    np.testing.assert_array_equal(f1.cpu().numpy(), want1)
+    c1 = int(s1.count.item())
+    assert c1 == int(want1.sum()) and sorted(s1.rows[:c1].cpu().tolist()) == np.flatnonzero(want1).tolist()
     # SpMM, row subset
     X = t(rs.standard_normal((n, d)).astype(np.float32))
     full = engine.spmm_csr(graph, X)
     sub = engine.spmm_csr_subset(graph, X, torch.full_like(X, 7.0), row_active=f0)
     on = f0.bool()
     assert torch.equal(sub[on], full[on]) and bool((sub[~on] == 7.0).all())
+    by_list = engine.spmm_csr_subset(graph, X, torch.full_like(X, 7.0), rows=s0)          # the set's list drives the launch
+    assert torch.equal(by_list, sub)
     # ... + column filter == the product with the unflagged rows of X zeroed; accumulate adds to what is there
     Xz = X * f1.float()[:, None]
     want = engine.spmm_csr(graph, Xz)
@@ -363,6 +371,9 @@ def test_frontier_and_subset_kernels(device):
     acc = engine.spmm_csr_subset(graph, X, torch.ones_like(X), row_active=f0, col_active=f1, accumulate=True)
     ref = engine.spmm_csr(graph, Xz, out=torch.ones_like(X), accumulate=True)
     assert torch.equal(acc[on], ref[on]) and bool((acc[~on] == 1.0).all())
+    # the scatter form of the same restricted product (backward of a layer whose dZ lives on few rows)
+    pushed = engine.spmm_csr_push_rows(graph, X, torch.zeros_like(X), s1)
+    torch.testing.assert_close(pushed, want, rtol=1e-4, atol=1e-5)
     # dense part over the row list
     E, Z = X, full
     W1, W2 = (t((rs.standard_normal((d, d)) * 0.2).astype(np.float32)) for _ in range(2))
@@ -380,9 +391,8 @@ def test_frontier_and_subset_kernels(device):
     torch.testing.assert_close(dW2_s, dW2_f, rtol=1e-4, atol=1e-5)
     # an empty batch: no flags, an empty list, nothing computed
     e = torch.zeros(0, dtype=torch.int64, device=device)
-    fe = engine.ngcf_frontier_mark(nu, ni, e, e, e)
-    se = engine.NGCFRowSet(fe, 0)
-    assert int(fe.sum()) == 0 and int(se.count.item()) == 0
+    se = engine.ngcf_frontier_mark(nu, ni, e, e, e)
+    assert int(se.flags.sum()) == 0 and int(se.count.item()) == 0
     assert bool((engine.ngcf_dense_fwd(E, Z, W1, W2, out=torch.full_like(E, 5.0), rows=se) == 5.0).all())
 
 
@@ -424,3 +434,69 @@ def test_batch_aware_propagation_equals_full_graph_propagation(device, tmp_path,
         scale = float(b[4][k].abs().max())
         torch.testing.assert_close(a[4][k], b[4][k], rtol=2e-4, atol=2e-6 * scale, msg=lambda m: f"{k}: {m}")
     assert float(a[4]["embedding.weight"].abs().sum()) > 0
+
+
+@pytest.mark.parametrize("batch,fraction,optimizer", [(24, 0.5, "adam"), (700, 0.5, "adamw"), (700, 0.0, "adam"), (24, 1e9, "adam")])
+def test_fused_step_equals_autograd_route(device, tmp_path, batch, fraction, optimizer):
+    """ngcf_step.NGCFStep (yr_ngcf_bpr_step: every launch of the step issued from C) against the autograd route
+    (bpr_forward, zero_grad, BPRLoss, backward, optimizer.step) over six steps on changing batches: the same
+    kernels on the same data — per-step losses bit-identical on the first step and equal to rounding after, all
+    parameters and both Adam moments equal to summation order, step counts equal; batch-aware propagation on
+    (small and medium batch), off, and forced on every layer; Adam and AdamW (weight decay)."""
+    from yelprecommendation_amd.graph import LaplacianCSR
+    from yelprecommendation_amd.loss import BPRLoss
+    from yelprecommendation_amd.models.ngcf import NGCF
+    from yelprecommendation_amd.ngcf_step import NGCFStep
+    from yelprecommendation_amd.optim import Adam, AdamW
+    from yelprecommendation_amd.utils import make_config
+    rs = np.random.RandomState(batch + 1)
+    nu, ni = 2300, 1900
+    u, i, r = _random_graph(rs, nu, ni, 9, hot_items=5)
+    graph = LaplacianCSR.from_interactions(u, i, r, nu, ni, device, heavy_threshold=128)
+    batches = [tuple(torch.from_numpy(rs.randint(0, m, batch + 3 * k)).to(device) for m in (nu, ni, ni)) for k in range(6)]
+    batches[3] = tuple(t[:0] for t in batches[3])                    # an empty batch: a step with zero gradients
+    out = {}
+    for route in ("fused", "autograd"):
+        torch.manual_seed(8)
+        cfg = make_config("NGCF", embed_size=64, num_orders=3, device="cuda", model_dir=str(tmp_path),
+                          ngcf_subset_fraction=fraction)
+        model = NGCF(cfg, nu, ni).to(device)
+        with torch.no_grad():
+            model.embedding.weight.mul_(0.1)
+        opt = (AdamW(model.parameters(), lr=2e-3, weight_decay=0.05) if optimizer == "adamw"
+               else Adam(model.parameters(), lr=2e-3))
+        losses = []
+        if route == "fused":
+            step = NGCFStep(model, opt, graph, fraction)
+            for bu, bp, bn in batches:
+                step.step(bu, bp, bn)
+                losses.append(float(step.last_loss().item()))
+            step.check()
+            assert abs(step.epoch_loss() - sum(losses)) <= 1e-6 * abs(sum(losses))
+        else:
+            for bu, bp, bn in batches:
+                if bu.numel() == 0:
+                    # the reference's loop on an empty batch: mean of nothing; here: a step with zero gradients
+                    for p in model.parameters():
+                        p.grad = torch.zeros_like(p)
+                    opt.step()
+                    losses.append(0.0)
+                    continue
+                pos, neg = model.bpr_forward(bu, bp, bn, graph)
+                opt.zero_grad()
+                loss = BPRLoss()(pos, neg)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.item()))
+        out[route] = (losses, {k: p.detach().clone() for k, p in model.named_parameters()},
+                      {k: (opt.state[p]["step"], opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone())
+                       for k, p in model.named_parameters()})
+    (la, pa, sa), (lb, pb, sb) = out["fused"], out["autograd"]
+    np.testing.assert_allclose(la[0], lb[0], rtol=3e-7)     # the same scores; the batch mean summed in another order
+    np.testing.assert_allclose(la, lb, rtol=2e-5)
+    for k in pa:
+        scale = float(pb[k].abs().max())
+        torch.testing.assert_close(pa[k], pb[k], rtol=1e-3, atol=1e-5 * scale, msg=lambda m: f"{k}: {m}")
+        assert sa[k][0] == sb[k][0] == 6
+        torch.testing.assert_close(sa[k][1], sb[k][1], rtol=1e-3, atol=1e-6 * float(sb[k][1].abs().max()), msg=lambda m: f"m {k}: {m}")
+        torch.testing.assert_close(sa[k][2], sb[k][2], rtol=1e-3, atol=1e-6 * float(sb[k][2].abs().max()), msg=lambda m: f"v {k}: {m}")

@@ -44,13 +44,17 @@ SIGNATURES = {
     "yr_ngcf_dense_fwd": [_p, _p, _p, _p, _i64, _int, _p, _p],
     "yr_ngcf_dense_bwd_data": [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p],
     "yr_ngcf_dense_bwd_weight": [_p, _p, _p, _p, _i64, _int, _p, _p, _p],
-    "yr_ngcf_frontier_mark": [_p, _p, _p, _i64, _i64, _i64, _p, _p],
-    "yr_ngcf_frontier_expand": [_p, _p, _i64, _p, _p, _p],
-    "yr_ngcf_frontier_list": [_p, _i64, _p, _p, _p],
-    "yr_spmm_csr_subset": [_p, _p, _p, _p, _p, _i64, _int, _int, _p, _i64, _int, _p, _p, _p],
+    "yr_ngcf_frontier_mark": [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p, _int, _p],
+    "yr_ngcf_frontier_expand": [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _int, _p],
+    "yr_spmm_csr_subset": [_p, _p, _p, _p, _p, _i64, _int, _int, _p, _i64, _int, _p, _p, _p, _p, _i64, _p],
+    "yr_spmm_csr_clustered": [_p, _p, _p, _p, _p, _i64, _int, _int, _p, _i64, _int, _p, _i64, _p, _p],
+    "yr_spmm_csr_push_rows": [_p, _p, _p, _p, _p, _i64, _int, _p, _p, _i64, _p],
     "yr_ngcf_dense_fwd_rows": [_p, _p, _p, _p, _i64, _int, _p, _p, _p, _i64, _p],
     "yr_ngcf_dense_bwd_data_rows": [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p, _p, _i64, _p],
     "yr_ngcf_dense_bwd_weight_rows": [_p, _p, _p, _p, _i64, _int, _p, _p, _p, _p, _i64, _p],
+    "yr_ngcf_step_workspace_bytes": [_i64, _int, _int, _i64],
+    "yr_ngcf_bpr_step": [_p, _p, _p, _i64, _i64, _p, _i64, _int, _i64, _p, _p, _p, _int, _int, _p, _p, _p, _i64,
+                         _d, _d, _d, _d, _d, _d, _d, _int, _d, _p, _i64, _p, _p, _p, _p],
     "yr_gemm_f32": [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _int, _int, _int, _p],
     "yr_gemm_f32_ex": [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _int, _int, _int, _p, _p, _p],
     "yr_cdae_decode_loss_partials": [_i64, _i64],
@@ -143,7 +147,8 @@ def load():
                       "yr_cdae_sparse_part_columns": C.c_int64,
                       "yr_cdae_decode_loss_partials": C.c_int64,
                       "yr_mf_eval_topk_workspace_bytes": C.c_int64,
-                      "yr_mf_eval_topk_planes_bytes": C.c_int64}.get(name, C.c_int)
+                      "yr_mf_eval_topk_planes_bytes": C.c_int64,
+                      "yr_ngcf_step_workspace_bytes": C.c_int64}.get(name, C.c_int)
     v = lib.yr_engine_version()
     if v != ENGINE_VERSION:
         raise EngineError(f"engine ABI version {v} != expected {ENGINE_VERSION}; rebuild the library")

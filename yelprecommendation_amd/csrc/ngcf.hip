@@ -40,7 +40,7 @@ template <int D, bool CF = false>
 __device__ __forceinline__ void spmm_accumulate(const int32_t* __restrict__ col, const float* __restrict__ val,
                                                 const float* __restrict__ Xl /* X + this lane's 4 floats */, int lo,
                                                 int hi, int first, int step, float4& acc,
-                                                const uint8_t* __restrict__ col_active = nullptr) {
+                                                const int32_t* __restrict__ col_active = nullptr) {
   int c[kSpmmUnroll];
   float w[kSpmmUnroll];
 #pragma unroll
@@ -86,8 +86,12 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int32_t* __restr
                                                           const float* __restrict__ val,
                                                           const float* __restrict__ X, float* __restrict__ Y,
                                                           int n, const int32_t* __restrict__ heavy, int n_heavy,
-                                                          int heavy_t, const uint8_t* __restrict__ row_active = nullptr,
-                                                          const uint8_t* __restrict__ col_active = nullptr) {
+                                                          int heavy_t, const int32_t* __restrict__ row_active = nullptr,
+                                                          const int32_t* __restrict__ col_active = nullptr,
+                                                          const int32_t* __restrict__ row_perm = nullptr,
+                                                          int chunk = 0,
+                                                          const int32_t* __restrict__ row_list = nullptr,
+                                                          const int32_t* __restrict__ row_count = nullptr) {
   constexpr int LPR = D / 4, GPW = kWave / LPR;
   __shared__ float4 s_acc[kWavesPerBlock][LPR];
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -126,9 +130,24 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int32_t* __restr
       __syncthreads();
     }
   } else {
-    const int nwaves = (gridDim.x - kSpmmHeavyBlocks) * kWavesPerBlock;
-    for (int row = (blockIdx.x - kSpmmHeavyBlocks) * kWavesPerBlock + wave; row < n; row += nwaves) {
-      if (SUB && row_active && !row_active[row]) continue;          // wave-uniform: one byte, then the next row
+    // Clustered order (yr_spmm_csr_clustered): row_perm holds 8 chunks of `chunk` rows (-1 = padding), chunk x =
+    // the rows of graph cluster x; the workgroups with blockIdx % 8 == x — the ones the dispatcher places on XCD x —
+    // walk chunk x, so that the neighbour rows a cluster's rows share stay in that XCD's 4 MiB L2.  A placement
+    // hint only: any placement gives the same result.
+    const int lb = blockIdx.x - kSpmmHeavyBlocks;
+    const int nwaves = (row_perm ? (gridDim.x - kSpmmHeavyBlocks) / 8 : gridDim.x - kSpmmHeavyBlocks) * kWavesPerBlock;
+    const int first = (row_perm ? lb >> 3 : lb) * kWavesPerBlock + wave;
+    // row_list (with row_active): the light rows come from the set's LIST, so a set of a few rows costs a few waves
+    // instead of one early-exiting wave per graph row (20 us for 96 rows at Yelp2018 size)
+    const int limit = row_perm ? chunk : ((SUB && row_list) ? *row_count : n);
+    for (int it = first; it < limit; it += nwaves) {
+      int row = it;
+      if (row_perm) {
+        row = row_perm[(lb & 7) * chunk + it];
+        if (row < 0) continue;
+      }
+      if (SUB && row_list) row = row_list[it];
+      else if (SUB && row_active && !row_active[row]) continue;     // wave-uniform: one flag, then the next row
       const int lo = rowptr[row], hi = rowptr[row + 1];
       if (hi - lo > heavy_t) continue;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -638,51 +657,100 @@ __global__ __launch_bounds__(kBlock) void ngcf_dense_bwd_weight_kernel(
   }
 }
 
+// Push form of Y += L X for a FEW source rows (the backward product of a layer whose dZ lives on the batch's rows
+// only): a wave per listed row r scatters val(r, j) * X[r] into Y[j] for every neighbour j with float atomics — L is
+// symmetric, so this is the pull product restricted to the columns in the list, at a cost proportional to the
+// list's non-zeros instead of the graph's.  Lane l of a group owns dims l, l + LPR, ... (every atomic instruction
+// covers LPR consecutive floats per row, see ngcf_score_bwd_kernel).
+constexpr int kPushParts = 16;     // workgroups per listed row: a popular item's row (thousands of non-zeros) is
+                                   // cut into this many slices, or one wave would walk it alone (measured: 128 us
+                                   // for 96 rows with a wave per row)
+template <int D>
+__global__ __launch_bounds__(kBlock) void spmm_push_rows_kernel(const int32_t* __restrict__ rowptr,
+                                                                const int32_t* __restrict__ col,
+                                                                const float* __restrict__ val,
+                                                                const float* __restrict__ X, float* __restrict__ Y,
+                                                                const int32_t* __restrict__ rows,
+                                                                const int32_t* __restrict__ count) {
+  constexpr int LPR = D / 4, GPW = kWave / LPR;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int grp = lane / LPR, l = lane % LPR;
+  const int64_t work = (int64_t)(*count) * kPushParts;
+  for (int64_t w = blockIdx.x; w < work; w += gridDim.x) {
+    const int row = rows[w / kPushParts], part = (int)(w % kPushParts);
+    const int lo = rowptr[row], len = rowptr[row + 1] - lo;
+    const int a = lo + (int)((int64_t)len * part / kPushParts), b = lo + (int)((int64_t)len * (part + 1) / kPushParts);
+    if (a == b) continue;
+    float x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = X[(int64_t)row * D + l + j * LPR];
+    for (int idx = a + wave * GPW + grp; idx < b; idx += kWavesPerBlock * GPW) {
+      const float wv = val[idx];
+      float* dst = Y + (int64_t)col[idx] * D + l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(dst + j * LPR, wv * x[j]);
+    }
+  }
+}
+
 // --------------------------------------------------------------------------- frontier of a batch
 // The scores of a batch read layer K at the rows R_K = {u} + {U + p} + {U + n} only (models/ngcf.py:37-39), layer
 // K-1 is then needed at R_K and its neighbours, and so on: S_K = R_K, S_{k-1} = S_k + N(S_k).  Flags are one byte
 // per node; the row list of a flag set is compacted with one counter atomic per wave (any order: every row is
 // computed on its own), its length stays on the device.
+// Wave-aggregated append of the lanes that flipped their node's flag 0 -> 1: one counter atomic per wave.
+__device__ __forceinline__ void frontier_append(bool won, int node, int32_t* __restrict__ rows,
+                                                int32_t* __restrict__ count) {
+  const unsigned long long m = __ballot(won);
+  if (m == 0) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int leader = __ffsll((long long)m) - 1;
+  int at = 0;
+  if (lane == leader) at = atomicAdd(count, __popcll(m));
+  at = __shfl(at, leader, kWave);
+  if (won) rows[at + __popcll(m & ((1ull << lane) - 1ull))] = node;
+}
+
 __global__ __launch_bounds__(kBlock) void ngcf_frontier_mark_kernel(const int64_t* __restrict__ user,
                                                                     const int64_t* __restrict__ pos,
                                                                     const int64_t* __restrict__ neg, int64_t B,
                                                                     int64_t num_users, int64_t num_items,
-                                                                    uint8_t* __restrict__ flags) {
-  for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += (int64_t)gridDim.x * kBlock) {
-    const int64_t u = user[b], p = pos[b], q = neg ? neg[b] : 0;
-    if (u >= 0 && u < num_users) flags[u] = 1;            // out-of-range ids: the score kernel raises the flag
-    if (p >= 0 && p < num_items) flags[num_users + p] = 1;
-    if (neg && q >= 0 && q < num_items) flags[num_users + q] = 1;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void ngcf_frontier_expand_kernel(const int32_t* __restrict__ rowptr,
-                                                                      const int32_t* __restrict__ col, int n,
-                                                                      const uint8_t* __restrict__ in,
-                                                                      uint8_t* __restrict__ out) {
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  const int nwaves = gridDim.x * kWavesPerBlock;
-  for (int row = blockIdx.x * kWavesPerBlock + wave; row < n; row += nwaves) {
-    if (!in[row]) continue;
-    if (lane == 0) out[row] = 1;
-    const int lo = rowptr[row], hi = rowptr[row + 1];
-    for (int idx = lo + lane; idx < hi; idx += kWave) out[col[idx]] = 1;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void ngcf_frontier_list_kernel(const uint8_t* __restrict__ flags, int n,
+                                                                    int32_t* __restrict__ flags,
                                                                     int32_t* __restrict__ rows,
                                                                     int32_t* __restrict__ count) {
-  const int lane = threadIdx.x & (kWave - 1);
-  for (int base = (blockIdx.x * kBlock + threadIdx.x) - lane; base < n; base += gridDim.x * kBlock) {
-    const int row = base + lane;
-    const bool on = row < n && flags[row];
-    const unsigned long long m = __ballot(on);
-    if (m == 0) continue;
-    int at = 0;
-    if (lane == 0) at = atomicAdd(count, __popcll(m));
-    at = __shfl(at, 0, kWave);
-    if (on) rows[at + __popcll(m & ((1ull << lane) - 1ull))] = row;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t b0 = (int64_t)blockIdx.x * kBlock; b0 < B; b0 += stride) {       // wave-uniform trip count
+    const int64_t b = b0 + threadIdx.x;
+    const bool in = b < B;
+    const int64_t u = in ? user[b] : -1, p = in ? pos[b] : -1, q = (in && neg) ? neg[b] : -1;
+    // out-of-range ids are skipped here: the score kernel raises the flag
+    const bool ou = u >= 0 && u < num_users, op = p >= 0 && p < num_items, oq = q >= 0 && q < num_items;
+    const int nu_ = (int)u, np_ = (int)(num_users + p), nq_ = (int)(num_users + q);
+    frontier_append(ou && atomicExch(flags + (ou ? nu_ : 0), 1) == 0, nu_, rows, count);
+    frontier_append(op && atomicExch(flags + (op ? np_ : 0), 1) == 0, np_, rows, count);
+    frontier_append(oq && atomicExch(flags + (oq ? nq_ : 0), 1) == 0, nq_, rows, count);
+  }
+}
+
+// out = in + neighbours(in): a wave per row of the input list
+__global__ __launch_bounds__(kBlock) void ngcf_frontier_expand_kernel(const int32_t* __restrict__ rowptr,
+                                                                      const int32_t* __restrict__ col,
+                                                                      const int32_t* __restrict__ rows_in,
+                                                                      const int32_t* __restrict__ count_in,
+                                                                      int32_t* __restrict__ flags,
+                                                                      int32_t* __restrict__ rows,
+                                                                      int32_t* __restrict__ count) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int cnt = *count_in;
+  for (int it = blockIdx.x * kWavesPerBlock + wave; it < cnt; it += gridDim.x * kWavesPerBlock) {
+    const int row = rows_in[it];
+    frontier_append(lane == 0 && atomicExch(flags + row, 1) == 0, row, rows, count);
+    const int lo = rowptr[row], hi = rowptr[row + 1];
+    for (int base = lo; base < hi; base += kWave) {                             // wave-uniform trip count
+      const int idx = base + lane;
+      const int j = idx < hi ? col[idx] : -1;
+      frontier_append(j >= 0 && atomicExch(flags + (j >= 0 ? j : 0), 1) == 0, j, rows, count);
+    }
   }
 }
 
@@ -723,64 +791,103 @@ extern "C" int yr_spmm_csr(const int32_t* rowptr, const int32_t* col, const floa
 
 extern "C" int yr_spmm_csr_subset(const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
                                   float* Y, int64_t n, int D, int accumulate, const int32_t* heavy_rows,
-                                  int64_t n_heavy, int heavy_threshold, const uint8_t* row_active,
-                                  const uint8_t* col_active, void* stream) {
+                                  int64_t n_heavy, int heavy_threshold, const int32_t* row_active,
+                                  const int32_t* col_active, const int32_t* row_list, const int32_t* row_count,
+                                  int64_t max_rows, void* stream) {
   if (n < 0 || n > 0x7fffffff || n_heavy < 0 || n_heavy > n) return YR_ERR_BADARG;
   if (n == 0) return 0;
   if (!rowptr || !X || !Y || X == Y) return YR_ERR_BADARG;
   if (n_heavy > 0 && !heavy_rows) return YR_ERR_BADARG;
+  if (row_list && (!row_active || !row_count || max_rows < 0 || max_rows > n)) return YR_ERR_BADARG;
   if (heavy_threshold <= 0 || n_heavy == 0) heavy_threshold = n_heavy > 0 ? 256 : 0x7fffffff;
-  int light = (int)((n + kWavesPerBlock - 1) / kWavesPerBlock);
+  int light = (int)(((row_list ? max_rows : n) + kWavesPerBlock - 1) / kWavesPerBlock);
   if (light > 65536) light = 65536;
+  if (light < 1) light = 1;
   const int grid = kSpmmHeavyBlocks + light;
   hipStream_t s = (hipStream_t)stream;
   if (accumulate) {
     YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_csr_kernel<kD, true, true>), dim3(grid), dim3(kBlock), 0, s, rowptr,
                                            col, val, X, Y, (int)n, heavy_rows, (int)n_heavy, heavy_threshold,
-                                           row_active, col_active));
+                                           row_active, col_active, nullptr, 0, row_list, row_count));
   } else {
     YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_csr_kernel<kD, false, true>), dim3(grid), dim3(kBlock), 0, s, rowptr,
                                            col, val, X, Y, (int)n, heavy_rows, (int)n_heavy, heavy_threshold,
-                                           row_active, col_active));
+                                           row_active, col_active, nullptr, 0, row_list, row_count));
   }
   return launch_status();
 }
 
-extern "C" int yr_ngcf_frontier_mark(const int64_t* user, const int64_t* pos, const int64_t* neg, int64_t B,
-                                     int64_t num_users, int64_t num_items, uint8_t* flags, void* stream) {
-  if (B < 0 || num_users <= 0 || num_items <= 0 || !flags) return YR_ERR_BADARG;
+extern "C" int yr_spmm_csr_clustered(const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
+                                     float* Y, int64_t n, int D, int accumulate, const int32_t* heavy_rows,
+                                     int64_t n_heavy, int heavy_threshold, const int32_t* row_perm, int64_t chunk,
+                                     const int32_t* row_active, void* stream) {
+  if (n < 0 || n > 0x7fffffff || n_heavy < 0 || n_heavy > n || chunk < 0 || chunk > n) return YR_ERR_BADARG;
+  if (n == 0) return 0;
+  if (!rowptr || !X || !Y || X == Y || !row_perm || chunk * 8 < n) return YR_ERR_BADARG;
+  if (n_heavy > 0 && !heavy_rows) return YR_ERR_BADARG;
+  if (heavy_threshold <= 0 || n_heavy == 0) heavy_threshold = n_heavy > 0 ? 256 : 0x7fffffff;
+  int per = (int)((chunk + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (per > 8192) per = 8192;
+  const int grid = kSpmmHeavyBlocks + 8 * per;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(flags, 0, (size_t)(num_users + num_items), s) != hipSuccess) return (int)hipGetLastError();
+  if (accumulate) {
+    YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_csr_kernel<kD, true, true>), dim3(grid), dim3(kBlock), 0, s, rowptr,
+                                           col, val, X, Y, (int)n, heavy_rows, (int)n_heavy, heavy_threshold,
+                                           row_active, nullptr, row_perm, (int)chunk));
+  } else {
+    YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_csr_kernel<kD, false, true>), dim3(grid), dim3(kBlock), 0, s, rowptr,
+                                           col, val, X, Y, (int)n, heavy_rows, (int)n_heavy, heavy_threshold,
+                                           row_active, nullptr, row_perm, (int)chunk));
+  }
+  return launch_status();
+}
+
+extern "C" int yr_spmm_csr_push_rows(const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
+                                     float* Y, int64_t n, int D, const int32_t* rows, const int32_t* count,
+                                     int64_t max_rows, void* stream) {
+  if (n < 0 || n > 0x7fffffff || max_rows < 0 || max_rows > n) return YR_ERR_BADARG;
+  if (n == 0 || max_rows == 0) return 0;
+  if (!rowptr || !col || !val || !X || !Y || X == Y || !rows || !count) return YR_ERR_BADARG;
+  int64_t g = max_rows * kPushParts;
+  const int grid = (int)(g > 32768 ? 32768 : g);
+  YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_push_rows_kernel<kD>), dim3(grid), dim3(kBlock), 0, (hipStream_t)stream,
+                                         rowptr, col, val, X, Y, rows, count));
+  return launch_status();
+}
+
+extern "C" int yr_ngcf_frontier_mark(const int64_t* user, const int64_t* pos, const int64_t* neg, int64_t B,
+                                     int64_t num_users, int64_t num_items, int32_t* flags, int32_t* rows,
+                                     int32_t* count, int clear, void* stream) {
+  if (B < 0 || num_users <= 0 || num_items <= 0 || num_users + num_items > 0x7fffffff || !flags || !rows || !count)
+    return YR_ERR_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (clear) {
+    if (hipMemsetAsync(flags, 0, (size_t)(num_users + num_items) * 4, s) != hipSuccess) return (int)hipGetLastError();
+    if (hipMemsetAsync(count, 0, 4, s) != hipSuccess) return (int)hipGetLastError();
+  }
   if (B == 0) return 0;
   if (!user || !pos) return YR_ERR_BADARG;
   hipLaunchKernelGGL(ngcf_frontier_mark_kernel, dim3(grid_for(B, kBlock)), dim3(kBlock), 0, s, user, pos, neg, B,
-                     num_users, num_items, flags);
+                     num_users, num_items, flags, rows, count);
   return launch_status();
 }
 
-extern "C" int yr_ngcf_frontier_expand(const int32_t* rowptr, const int32_t* col, int64_t n, const uint8_t* flags_in,
-                                       uint8_t* flags_out, void* stream) {
-  if (n < 0 || n > 0x7fffffff) return YR_ERR_BADARG;
-  if (n == 0) return 0;
-  if (!rowptr || !col || !flags_in || !flags_out || flags_in == flags_out) return YR_ERR_BADARG;
+extern "C" int yr_ngcf_frontier_expand(const int32_t* rowptr, const int32_t* col, int64_t n, const int32_t* rows_in,
+                                       const int32_t* count_in, int64_t max_rows_in, int32_t* flags, int32_t* rows,
+                                       int32_t* count, int clear, void* stream) {
+  if (n < 0 || n > 0x7fffffff || max_rows_in < 0 || max_rows_in > n) return YR_ERR_BADARG;
+  if (!flags || !rows || !count) return YR_ERR_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(flags_out, 0, (size_t)n, s) != hipSuccess) return (int)hipGetLastError();
-  int grid = (int)((n + kWavesPerBlock - 1) / kWavesPerBlock);
-  if (grid > 65536) grid = 65536;
-  hipLaunchKernelGGL(ngcf_frontier_expand_kernel, dim3(grid), dim3(kBlock), 0, s, rowptr, col, (int)n, flags_in,
-                     flags_out);
-  return launch_status();
-}
-
-extern "C" int yr_ngcf_frontier_list(const uint8_t* flags, int64_t n, int32_t* rows, int32_t* count, void* stream) {
-  if (n < 0 || n > 0x7fffffff) return YR_ERR_BADARG;
-  if (!count) return YR_ERR_BADARG;
-  hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(count, 0, sizeof(int32_t), s) != hipSuccess) return (int)hipGetLastError();
-  if (n == 0) return 0;
-  if (!flags || !rows) return YR_ERR_BADARG;
-  hipLaunchKernelGGL(ngcf_frontier_list_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, flags, (int)n, rows,
-                     count);
+  if (clear) {
+    if (n && hipMemsetAsync(flags, 0, (size_t)n * 4, s) != hipSuccess) return (int)hipGetLastError();
+    if (hipMemsetAsync(count, 0, 4, s) != hipSuccess) return (int)hipGetLastError();
+  }
+  if (n == 0 || max_rows_in == 0) return 0;
+  if (!rowptr || !col || !rows_in || !count_in || rows_in == rows) return YR_ERR_BADARG;
+  int grid = (int)((max_rows_in + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(ngcf_frontier_expand_kernel, dim3(grid), dim3(kBlock), 0, s, rowptr, col, rows_in, count_in, flags,
+                     rows, count);
   return launch_status();
 }
 

@@ -255,57 +255,99 @@ def _ptr_array(tensors, what):
 
 
 class NGCFRowSet:
-    """A set of graph nodes for the batch-aware propagation: ``flags`` uint8[N] (1 = member), ``rows`` int32[N]
-    of which the first ``count[0]`` entries list the members (count stays on the device), ``max_rows`` the
-    host's upper bound of the count (sizes grids only)."""
-    __slots__ = ("flags", "rows", "count", "max_rows")
+    """A set of graph nodes for the batch-aware propagation: ``flags`` int32[N] (1 = member), ``rows`` int32[N]
+    of which the first ``count[0]`` entries list the members in no particular order (the count stays on the device),
+    ``max_rows`` the host's upper bound of the count (sizes grids only); ``push``: few rows — the backward product
+    scatters from them (spmm_csr_push_rows)."""
+    __slots__ = ("flags", "rows", "count", "max_rows", "push")
 
-    def __init__(self, flags, max_rows):
-        lib = _lib.load()
-        n = flags.numel()
-        self.flags, self.max_rows = flags, int(min(max_rows, n))
-        self.rows = torch.empty(n, dtype=torch.int32, device=flags.device)
-        self.count = torch.empty(1, dtype=torch.int32, device=flags.device)
-        check(lib.yr_ngcf_frontier_list(_dev(flags, torch.uint8, "flags"), n, self.rows.data_ptr(),
-                                        self.count.data_ptr(), _stream()), "yr_ngcf_frontier_list")
+    def __init__(self, n, device, max_rows, push=False):
+        self.flags = torch.empty(n, dtype=torch.int32, device=device)
+        self.rows = torch.empty(n, dtype=torch.int32, device=device)
+        self.count = torch.empty(1, dtype=torch.int32, device=device)
+        self.max_rows, self.push = int(min(max_rows, n)), bool(push)
 
 
-def ngcf_frontier_mark(num_users, num_items, user_id, pos_ids, neg_ids=None):
-    """uint8[num_users + num_items] flags of the rows a batch's scores read: user_id, num_users + pos_ids,
-    num_users + neg_ids (reference models/ngcf.py:31-32,37-39)."""
+def ngcf_frontier_mark(num_users, num_items, user_id, pos_ids, neg_ids=None, max_rows=None, push=False):
+    """The rows a batch's scores read — user_id, num_users + pos_ids, num_users + neg_ids (reference
+    models/ngcf.py:31-32,37-39) — as an NGCFRowSet."""
     lib = _lib.load()
     i64 = torch.int64
-    flags = torch.empty(num_users + num_items, dtype=torch.uint8, device=user_id.device)
-    check(lib.yr_ngcf_frontier_mark(_dev(user_id, i64, "user_id"), _dev(pos_ids, i64, "pos_ids"),
-                                    _dev(neg_ids, i64, "neg_ids") if neg_ids is not None else None, user_id.numel(),
-                                    num_users, num_items, flags.data_ptr(), _stream()), "yr_ngcf_frontier_mark")
-    return flags
+    B = user_id.numel()
+    out = NGCFRowSet(num_users + num_items, user_id.device, (2 if neg_ids is None else 3) * B if max_rows is None else max_rows, push)
+    check(lib.yr_ngcf_frontier_mark(_dev(user_id, i64, "user_id") if B else None, _dev(pos_ids, i64, "pos_ids") if B else None,
+                                    _dev(neg_ids, i64, "neg_ids") if (neg_ids is not None and B) else None, B,
+                                    num_users, num_items, out.flags.data_ptr(), out.rows.data_ptr(), out.count.data_ptr(),
+                                    1, _stream()), "yr_ngcf_frontier_mark")
+    return out
 
 
-def ngcf_frontier_expand(graph, flags):
-    """flags of the given rows plus all their neighbours in the graph."""
+def ngcf_frontier_expand(graph, rows, max_rows=None, push=False):
+    """The given NGCFRowSet plus all neighbours of its rows in the graph, as a new NGCFRowSet."""
     lib = _lib.load()
-    out = torch.empty_like(flags)
+    out = NGCFRowSet(graph.n, rows.flags.device, graph.n if max_rows is None else max_rows, push)
     check(lib.yr_ngcf_frontier_expand(_dev(graph.rowptr, torch.int32, "rowptr"), _dev(graph.col, torch.int32, "col"),
-                                      graph.n, _dev(flags, torch.uint8, "flags"), out.data_ptr(), _stream()),
+                                      graph.n, rows.rows.data_ptr(), rows.count.data_ptr(), rows.max_rows,
+                                      out.flags.data_ptr(), out.rows.data_ptr(), out.count.data_ptr(), 1, _stream()),
           "yr_ngcf_frontier_expand")
     return out
 
 
-def spmm_csr_subset(graph, X, out, row_active=None, col_active=None, accumulate=False):
+def spmm_csr_subset(graph, X, out, row_active=None, col_active=None, accumulate=False, rows=None):
     """:func:`spmm_csr` on the rows flagged in ``row_active`` (None: all) and, with ``col_active``, over the
-    flagged neighbours only; other rows of ``out`` are left as they are."""
+    flagged neighbours only; other rows of ``out`` are left as they are.  ``rows`` (NGCFRowSet, instead of
+    ``row_active``): the same with the set's list driving the launch (cheap for small sets)."""
+    if rows is not None:
+        row_active = rows.flags
     lib = _lib.load()
     n, d = X.shape
     if n != graph.n or out.shape != X.shape:
         raise EngineError(f"X / out must be [{graph.n}, D]")
-    u8 = torch.uint8
+    u8 = torch.int32                                   # the row sets' flags
     check(lib.yr_spmm_csr_subset(_dev(graph.rowptr, torch.int32, "rowptr"), _dev(graph.col, torch.int32, "col"),
                                  _dev(graph.val, torch.float32, "val"), _dev(X, torch.float32, "X"),
                                  _dev(out, torch.float32, "Y"), n, d, 1 if accumulate else 0,
                                  _opt(graph.heavy_rows, torch.int32, "heavy_rows"), graph.n_heavy, graph.heavy_threshold,
-                                 _opt(row_active, u8, "row_active"), _opt(col_active, u8, "col_active"), _stream()),
+                                 _opt(row_active, u8, "row_active"), _opt(col_active, u8, "col_active"),
+                                 None if rows is None else rows.rows.data_ptr(),
+                                 None if rows is None else rows.count.data_ptr(), 0 if rows is None else rows.max_rows,
+                                 _stream()),
           "yr_spmm_csr_subset")
+    return out
+
+
+def spmm_csr_push_rows(graph, X, out, rows):
+    """out[j] += sum over the rows r of ``rows`` (NGCFRowSet) of L[r, j] * X[r]: for the symmetric L the product
+    out += L X restricted to those columns, as a scatter from the listed rows (yr_spmm_csr_push_rows)."""
+    lib = _lib.load()
+    n, d = X.shape
+    if n != graph.n or out.shape != X.shape:
+        raise EngineError(f"X / out must be [{graph.n}, D]")
+    check(lib.yr_spmm_csr_push_rows(_dev(graph.rowptr, torch.int32, "rowptr"), _dev(graph.col, torch.int32, "col"),
+                                    _dev(graph.val, torch.float32, "val"), _dev(X, torch.float32, "X"),
+                                    _dev(out, torch.float32, "Y"), n, d, rows.rows.data_ptr(), rows.count.data_ptr(),
+                                    rows.max_rows, _stream()), "yr_spmm_csr_push_rows")
+    return out
+
+
+def spmm_csr_clustered(graph, X, row_perm, chunk, out=None, accumulate=False, row_active=None):
+    """:func:`spmm_csr` with the rows visited cluster by cluster, one cluster per XCD (``graph.cluster_order``)."""
+    lib = _lib.load()
+    n, d = X.shape
+    if n != graph.n:
+        raise EngineError(f"X has {n} rows, the graph {graph.n}")
+    if out is None:
+        if accumulate:
+            raise EngineError("accumulate needs an output buffer")
+        out = torch.empty_like(X)
+    if row_perm.numel() != 8 * chunk:
+        raise EngineError("row_perm must hold 8 chunks")
+    check(lib.yr_spmm_csr_clustered(_dev(graph.rowptr, torch.int32, "rowptr"), _dev(graph.col, torch.int32, "col"),
+                                    _dev(graph.val, torch.float32, "val"), _dev(X, torch.float32, "X"),
+                                    _dev(out, torch.float32, "Y"), n, d, 1 if accumulate else 0,
+                                    _opt(graph.heavy_rows, torch.int32, "heavy_rows"), graph.n_heavy,
+                                    graph.heavy_threshold, _dev(row_perm, torch.int32, "row_perm"), int(chunk),
+                                    _opt(row_active, torch.int32, "row_active"), _stream()), "yr_spmm_csr_clustered")
     return out
 
 

@@ -53,7 +53,7 @@ class _NGCFScores(torch.autograd.Function):
             else:
                 # rows outside the set stay unwritten: nothing downstream reads them (the next layer's set and
                 # its neighbours lie inside this one)
-                Z = engine.spmm_csr_subset(graph, layers[-1], torch.empty_like(E0d), row_active=sets[k].flags)
+                Z = engine.spmm_csr_subset(graph, layers[-1], torch.empty_like(E0d), rows=sets[k])
                 out = engine.ngcf_dense_fwd(layers[-1], Z, W1s[k].detach(), W2s[k].detach(), rows=sets[k])
             Zs.append(Z)
             layers.append(out)
@@ -93,17 +93,23 @@ class _NGCFScores(torch.autograd.Function):
             dW1s[k], dW2s[k] = dWstack[k], dWstack[K + k]
             # dlayers[k] += dA + dH * Z ; dZ = dA + dH * E ; then dlayers[k] += L^T dZ (L symmetric)
             cur = ctx.sets[k]
+            dZ = None if cur is None or cur.push else torch.zeros_like(layers[k])
             dZ = engine.ngcf_dense_bwd(dlayers[k + 1], layers[k + 1], layers[k], Zs[k], W1s[k], W2s[k],
-                                       dlayers[k], dW1s[k], dW2s[k], W1T=WT[k], W2T=WT[K + k], rows=cur)
+                                       dlayers[k], dW1s[k], dW2s[k], dZ=dZ, W1T=WT[k], W2T=WT[K + k], rows=cur)
             if cur is None:
                 engine.spmm_csr(graph, dZ, out=dlayers[k], accumulate=True)
+            elif cur.push:
+                # few rows: they scatter into their neighbours (cost = their non-zeros, not the graph's)
+                engine.spmm_csr_push_rows(graph, dZ, dlayers[k], cur)
             else:
-                # dZ is non-zero (and written) on this layer's set only: gather those neighbours, and only into
-                # the rows of the layer below's set (which holds every neighbour of this one)
+                # dZ is non-zero on this layer's set only (zero-filled elsewhere): the pull product, into the rows of
+                # the set of the layer below alone (it holds every neighbour of this one)
                 below = ctx.sets[k - 1] if k > 0 else None
-                engine.spmm_csr_subset(graph, dZ, dlayers[k], row_active=None if below is None else below.flags,
-                                       col_active=cur.flags, accumulate=True)
+                engine.spmm_csr_subset(graph, dZ, dlayers[k], rows=below, accumulate=True)
         return (None, None, None, None, None, None, None, dlayers[0], *dW1s, *dW2s)
+
+
+PUSH_MAX_PAIRS = 50000       # as kPushMaxPairs of csrc/ngcf_step.hip: scatter form of the backward product below this
 
 
 def _subset_plan(graph, num_users, K, user_id, pos_ids, neg_ids, fraction):
@@ -114,14 +120,15 @@ def _subset_plan(graph, num_users, K, user_id, pos_ids, neg_ids, fraction):
     n = graph.n
     est = min(n, user_id.numel() * (2 if neg_ids is None else 3))
     hop = 1.0 + graph.nnz / max(n, 1)
-    flags = None
+    cur = None
     for k in range(K - 1, -1, -1):
         if est > fraction * n:
             break
-        flags = (engine.ngcf_frontier_mark(num_users, n - num_users, user_id, pos_ids, neg_ids) if flags is None
-                 else engine.ngcf_frontier_expand(graph, flags))
         # the last layer's set has at most `est` rows (exact bound); a deeper set's size is not known on the host
-        sets[k] = engine.NGCFRowSet(flags, est if k == K - 1 else n)
+        push = est * hop <= PUSH_MAX_PAIRS
+        cur = (engine.ngcf_frontier_mark(num_users, n - num_users, user_id, pos_ids, neg_ids, max_rows=est, push=push)
+               if cur is None else engine.ngcf_frontier_expand(graph, cur, push=push))
+        sets[k] = cur
         est = min(n, int(est * hop))
     return sets
 

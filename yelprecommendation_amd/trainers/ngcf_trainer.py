@@ -4,7 +4,9 @@ Same constructor ``NGCFTrainer(cfg, num_items, num_users, laplacian_matrix)`` an
 ``run / train / validate / evaluate`` contract.  ``evaluate`` scores
 ``np.random.randint(len(eval_data), size=100)`` eval rows — WITH replacement, drawn from the global
 NumPy RNG exactly like the reference (ngcf_trainer.py:140) — but propagates the graph once per
-call instead of once per sampled user.
+call instead of once per sampled user.  With Adam / AdamW ``train`` runs every batch as ONE engine call
+(ngcf_step.NGCFStep: the launches of the autograd route, issued from C; cfg.fused_step=False keeps the reference's
+loop shape — bpr_forward, zero_grad, loss, backward, step — on the HIP autograd ops).
 """
 import numpy as np
 import torch
@@ -70,9 +72,29 @@ class NGCFTrainer(BaseTrainer):
         p[:1].copy_(loss.detach().reshape(1))
         return p
 
+    def _fused_step(self):
+        """The whole batch step as one engine call (ngcf_step.NGCFStep) for Adam / AdamW unless
+        cfg.fused_step is False; None -> the launch-by-launch autograd route below (SGD, or on request)."""
+        from .. import optim
+        from ..ngcf_step import NGCFStep
+        if not isinstance(self.optimizer, optim.Adam) or not self.cfg.get("fused_step", True):
+            return None
+        graph = self.model.graph(self.laplacian_matrix)
+        st = getattr(self, "_step", None)
+        if st is None or not st.bound_to(self.model, self.optimizer, graph):
+            st = self._step = NGCFStep(self.model, self.optimizer, graph, self.model._subset_fraction())
+        return st
+
     def train(self, train_dataloader) -> float:
         # reference ngcf_trainer.py:102-117
         self.model.train()
+        step = self._fused_step()
+        if step is not None:
+            step.loss_accum.zero_()
+            for data in train_dataloader:
+                step.step(*self._batch(data))
+            step.check()
+            return step.epoch_loss()
         self._loss_accum.zero_()
         for data in train_dataloader:
             user_id, pos_item, neg_item = self._batch(data)
