@@ -305,6 +305,14 @@ int yr_spmm_csr_subset(const int32_t *rowptr, const int32_t *col, const float *v
                        const int32_t *heavy_rows, int64_t n_heavy, int heavy_threshold,
                        const int32_t *row_active, const int32_t *col_active,
                        const int32_t *row_list, const int32_t *row_count, int64_t max_rows, void *stream);
+/* yr_spmm_csr_tiled: the same product with a workgroup per TILE of consecutive rows: tile_ptr int32[n_tiles + 1],
+ * tile t = rows [tile_ptr[t], tile_ptr[t + 1]) — at most 32 rows whose non-zeros, not counting rows longer than
+ * heavy_threshold (<= 2048), number at most 2048; the tiles cover 0 .. n-1 in order.  The tile's index data is
+ * staged in LDS once and the gathers of consecutive rows are pipelined.  Same results as yr_spmm_csr bit for bit. */
+int yr_spmm_csr_tiled(const int32_t *rowptr, const int32_t *col, const float *val,
+                      const float *X, float *Y, int64_t n, int D, int accumulate,
+                      const int32_t *heavy_rows, int64_t n_heavy, int heavy_threshold,
+                      const int32_t *tile_ptr, int64_t n_tiles, void *stream);
 /* yr_spmm_csr_clustered: yr_spmm_csr_subset with the rows visited in a clustered order — row_perm: int32[8 * chunk],
  * chunk x (x = 0..7) lists the rows of graph cluster x, padded with -1; every row exactly once overall.  The
  * workgroups the dispatcher places on XCD x (blockIdx % 8 == x) walk chunk x, so the neighbour rows that the rows

@@ -38,7 +38,14 @@ if not only:
     b = engine.spmm_csr_clustered(graph, X, perm, chunk)
     c = engine.spmm_csr_clustered(graph, X, rnd, chunk)
     print("identical to the index-order product:", torch.equal(a, b), torch.equal(a, c))
+tl = graph.tiles()
+d = engine.spmm_csr_tiled(graph, X)
+print("tiles:", tl.numel() - 1, "tiled identical:", torch.equal(engine.spmm_csr(graph, X), d))
+acc1 = engine.spmm_csr(graph, X, out=torch.ones_like(X), accumulate=True)
+acc2 = engine.spmm_csr_tiled(graph, X, out=torch.ones_like(X), accumulate=True)
+print("tiled accumulate identical:", torch.equal(acc1, acc2))
 for name, f in (("index order", lambda: engine.spmm_csr(graph, X)),
+                ("tiled", lambda: engine.spmm_csr_tiled(graph, X)),
                 ("clustered, cluster x on XCD x", lambda: engine.spmm_csr_clustered(graph, X, perm, chunk)),
                 ("random rows per XCD (control)", lambda: engine.spmm_csr_clustered(graph, X, rnd, chunk))):
     if only and not name.startswith(only):

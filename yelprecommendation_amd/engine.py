@@ -330,6 +330,26 @@ def spmm_csr_push_rows(graph, X, out, rows):
     return out
 
 
+def spmm_csr_tiled(graph, X, out=None, accumulate=False):
+    """:func:`spmm_csr` in the tiled form (yr_spmm_csr_tiled): a workgroup per tile of consecutive rows, index data
+    staged in LDS, gathers of consecutive rows pipelined."""
+    lib = _lib.load()
+    n, d = X.shape
+    if n != graph.n:
+        raise EngineError(f"X has {n} rows, the graph {graph.n}")
+    if out is None:
+        if accumulate:
+            raise EngineError("accumulate needs an output buffer")
+        out = torch.empty_like(X)
+    tiles = graph.tiles()
+    check(lib.yr_spmm_csr_tiled(_dev(graph.rowptr, torch.int32, "rowptr"), _dev(graph.col, torch.int32, "col"),
+                                _dev(graph.val, torch.float32, "val"), _dev(X, torch.float32, "X"),
+                                _dev(out, torch.float32, "Y"), n, d, 1 if accumulate else 0,
+                                _opt(graph.heavy_rows, torch.int32, "heavy_rows"), graph.n_heavy, graph.heavy_threshold,
+                                _dev(tiles, torch.int32, "tile_ptr"), tiles.numel() - 1, _stream()), "yr_spmm_csr_tiled")
+    return out
+
+
 def spmm_csr_clustered(graph, X, row_perm, chunk, out=None, accumulate=False, row_active=None):
     """:func:`spmm_csr` with the rows visited cluster by cluster, one cluster per XCD (``graph.cluster_order``)."""
     lib = _lib.load()

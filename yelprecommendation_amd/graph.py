@@ -37,6 +37,30 @@ class LaplacianCSR:
         order = np.concatenate([np.argsort(-deg[:split], kind="stable"), split + np.argsort(-deg[split:], kind="stable")])
         self.row_order = torch.from_numpy(order.astype(np.int32)).to(device)
 
+    def tiles(self, max_rows=32, max_nnz=2048):
+        """int32 tile_ptr [n_tiles + 1] on the device for yr_spmm_csr_tiled: consecutive rows cut greedily so that a
+        tile has at most ``max_rows`` rows and ``max_nnz`` non-zeros (rows longer than the heavy threshold count as
+        empty: the kernel's first workgroups own them)."""
+        cached = getattr(self, "_tiles", None)
+        if cached is not None and cached[0] == (max_rows, max_nnz):
+            return cached[1]
+        deg = np.diff(self.rowptr.cpu().numpy().astype(np.int64))
+        deg = np.where(deg > self.heavy_threshold, 0, deg)
+        if deg.size and deg.max() > max_nnz:
+            raise ValueError("a light row does not fit a tile")
+        cum = np.concatenate([[0], np.cumsum(deg)])
+        cuts, r = [0], 0
+        n = self.n
+        while r < n:
+            hi = min(n, r + max_rows)
+            # the furthest end <= hi whose non-zeros fit
+            end = int(np.searchsorted(cum, cum[r] + max_nnz, side="right")) - 1
+            r = max(r + 1, min(hi, end))
+            cuts.append(r)
+        out = torch.from_numpy(np.asarray(cuts, dtype=np.int32)).to(self.rowptr.device)
+        self._tiles = ((max_rows, max_nnz), out)
+        return out
+
     def cluster_order(self, split, clusters=8, iters=6, seed=0):
         """(row_perm int32[clusters * chunk] on the device, chunk) for yr_spmm_csr_clustered: a balanced
         co-clustering of the bipartite graph (users = nodes below ``split``).  Alternating label propagation — a
