@@ -287,9 +287,9 @@ int yr_ngcf_dense_bwd_weight(const float *dEout, const float *Eout, const float 
  * yr_ngcf_frontier_expand: the set (flags, rows, count) += the rows rows_in[0 .. *count_in) and all their
  *   neighbours in the CSR; max_rows_in (<= n) = the host's upper bound of *count_in (sizes the grid).
  * yr_spmm_csr_subset: yr_spmm_csr restricted to the rows with row_active[row] != 0 (int32 flags; other rows of Y
- *   untouched; NULL = all rows) and, with col_active, to the neighbours with col_active[col] != 0.  row_list /
- *   row_count / max_rows (optional, with row_active): the same set as a list — the rows with at most
- *   heavy_threshold non-zeros are then taken from the list (a set of a few rows costs a few waves).
+ *   untouched; NULL = all rows).  row_list / row_count / max_rows (optional, with row_active): the same set as a
+ *   list — the rows with at most heavy_threshold non-zeros are then taken from the list (a set of a few rows
+ *   costs a few waves instead of one early-exiting wave per graph row).
  * yr_ngcf_dense_{fwd,bwd_data,bwd_weight}_rows: the dense part of a layer over the rows rows[0 .. *count) instead
  *   of 0 .. n-1; max_rows (<= n) is the host's upper bound of *count and only sizes the grid (the workgroups
  *   stride over the list, so any count up to n is covered).
@@ -303,24 +303,8 @@ int yr_ngcf_frontier_expand(const int32_t *rowptr, const int32_t *col, int64_t n
 int yr_spmm_csr_subset(const int32_t *rowptr, const int32_t *col, const float *val,
                        const float *X, float *Y, int64_t n, int D, int accumulate,
                        const int32_t *heavy_rows, int64_t n_heavy, int heavy_threshold,
-                       const int32_t *row_active, const int32_t *col_active,
+                       const int32_t *row_active,
                        const int32_t *row_list, const int32_t *row_count, int64_t max_rows, void *stream);
-/* yr_spmm_csr_tiled: the same product with a workgroup per TILE of consecutive rows: tile_ptr int32[n_tiles + 1],
- * tile t = rows [tile_ptr[t], tile_ptr[t + 1]) — at most 32 rows whose non-zeros, not counting rows longer than
- * heavy_threshold (<= 2048), number at most 2048; the tiles cover 0 .. n-1 in order.  The tile's index data is
- * staged in LDS once and the gathers of consecutive rows are pipelined.  Same results as yr_spmm_csr bit for bit. */
-int yr_spmm_csr_tiled(const int32_t *rowptr, const int32_t *col, const float *val,
-                      const float *X, float *Y, int64_t n, int D, int accumulate,
-                      const int32_t *heavy_rows, int64_t n_heavy, int heavy_threshold,
-                      const int32_t *tile_ptr, int64_t n_tiles, void *stream);
-/* yr_spmm_csr_clustered: yr_spmm_csr_subset with the rows visited in a clustered order — row_perm: int32[8 * chunk],
- * chunk x (x = 0..7) lists the rows of graph cluster x, padded with -1; every row exactly once overall.  The
- * workgroups the dispatcher places on XCD x (blockIdx % 8 == x) walk chunk x, so the neighbour rows that the rows
- * of one cluster share stay in that XCD's L2.  Same results as yr_spmm_csr for any row_perm / placement. */
-int yr_spmm_csr_clustered(const int32_t *rowptr, const int32_t *col, const float *val,
-                          const float *X, float *Y, int64_t n, int D, int accumulate,
-                          const int32_t *heavy_rows, int64_t n_heavy, int heavy_threshold,
-                          const int32_t *row_perm, int64_t chunk, const int32_t *row_active, void *stream);
 /* yr_spmm_csr_push_rows: Y[j] += sum over the listed rows r of L[r, j] * X[r] — for a symmetric L the product
  * Y += L X restricted to the columns rows[0 .. *count), as a scatter from those rows (float atomics); the cost is
  * the list's non-zeros, not the graph's.  The backward product of a layer whose dZ lives on a few rows. */

@@ -324,7 +324,7 @@ def test_frontier_and_subset_kernels(device):
     """The batch-aware propagation's building blocks (ABI v28): frontier flags == the NumPy definition
     S_K = {u, U + p, U + n}, S_{k-1} = S_k + neighbours(S_k); the row list is a permutation of the flagged rows with
     its length on the device; the row-subset SpMM writes EXACTLY the full product's rows (bit for bit) and nothing
-    else; with the column filter it equals the product of a matrix whose unflagged rows are zero; the row-list
+    else; the scatter form from a row list equals the product of a matrix whose other rows are zero; the row-list
     forms of the dense kernels equal the full kernels on the listed rows bit for bit."""
     from yelprecommendation_amd import engine
     from yelprecommendation_amd.graph import LaplacianCSR, laplacian_scipy
@@ -363,14 +363,12 @@ def test_frontier_and_subset_kernels(device):
     assert torch.equal(sub[on], full[on]) and bool((sub[~on] == 7.0).all())
     by_list = engine.spmm_csr_subset(graph, X, torch.full_like(X, 7.0), rows=s0)          # the set's list drives the launch
     assert torch.equal(by_list, sub)
-    # ... + column filter == the product with the unflagged rows of X zeroed; accumulate adds to what is there
+    # accumulate adds to what is there, on the flagged rows only
+    acc = engine.spmm_csr_subset(graph, X, torch.ones_like(X), row_active=f0, accumulate=True)
+    ref = engine.spmm_csr(graph, X, out=torch.ones_like(X), accumulate=True)
+    assert torch.equal(acc[on], ref[on]) and bool((acc[~on] == 1.0).all())
     Xz = X * f1.float()[:, None]
     want = engine.spmm_csr(graph, Xz)
-    got = engine.spmm_csr_subset(graph, X, torch.zeros_like(X), row_active=None, col_active=f1)
-    assert torch.equal(got, want)
-    acc = engine.spmm_csr_subset(graph, X, torch.ones_like(X), row_active=f0, col_active=f1, accumulate=True)
-    ref = engine.spmm_csr(graph, Xz, out=torch.ones_like(X), accumulate=True)
-    assert torch.equal(acc[on], ref[on]) and bool((acc[~on] == 1.0).all())
     # the scatter form of the same restricted product (backward of a layer whose dZ lives on few rows)
     pushed = engine.spmm_csr_push_rows(graph, X, torch.zeros_like(X), s1)
     torch.testing.assert_close(pushed, want, rtol=1e-4, atol=1e-5)

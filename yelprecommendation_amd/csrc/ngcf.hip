@@ -33,14 +33,10 @@ constexpr int kSpmmHeavyBlocks = 256;
 // One lane group's share of a CSR row: neighbours lo+first, lo+first+step, ...  The column/value
 // pairs of the NEXT round are fetched before this round's rows are gathered (two dependent
 // latencies per round otherwise), and slots past the row end issue no row load at all.
-// CF (column filter, the row-subset form below): a neighbour whose `col_active` byte is 0 is skipped like a slot
-// past the row end — its row of X is known to be all zero (or not computed) and is never fetched.  The flag is
-// read where the column index is, one round ahead of the gather.
-template <int D, bool CF = false>
+template <int D>
 __device__ __forceinline__ void spmm_accumulate(const int32_t* __restrict__ col, const float* __restrict__ val,
                                                 const float* __restrict__ Xl /* X + this lane's 4 floats */, int lo,
-                                                int hi, int first, int step, float4& acc,
-                                                const int32_t* __restrict__ col_active = nullptr) {
+                                                int hi, int first, int step, float4& acc) {
   int c[kSpmmUnroll];
   float w[kSpmmUnroll];
 #pragma unroll
@@ -49,7 +45,6 @@ __device__ __forceinline__ void spmm_accumulate(const int32_t* __restrict__ col,
     const bool ok = idx < hi;
     c[q] = ok ? col[idx] : -1;
     w[q] = ok ? val[idx] : 0.0f;
-    if (CF && ok && !col_active[c[q]]) c[q] = -1;
   }
   for (int base = lo; base < hi; base += step * kSpmmUnroll) {
     float4 r[kSpmmUnroll];
@@ -66,8 +61,7 @@ __device__ __forceinline__ void spmm_accumulate(const int32_t* __restrict__ col,
       const bool ok = idx < hi;
       c[q] = ok ? col[idx] : -1;
       w[q] = ok ? val[idx] : 0.0f;
-      if (CF && ok && !col_active[c[q]]) c[q] = -1;
-    }
+      }
 #pragma unroll
     for (int q = 0; q < kSpmmUnroll; ++q) {
       acc.x = fmaf(wc[q], r[q].x, acc.x); acc.y = fmaf(wc[q], r[q].y, acc.y);
@@ -76,10 +70,8 @@ __device__ __forceinline__ void spmm_accumulate(const int32_t* __restrict__ col,
   }
 }
 
-// SUB (row-subset form, yr_spmm_csr_subset): only the rows whose `row_active` byte is set are computed (the others
-// are left untouched), and with `col_active` only the neighbours whose byte is set are gathered.  A computed row
-// goes through exactly the instructions of the full form, so its result is bit-identical to the full product's
-// whenever the skipped neighbours' rows of X are zero (or, forward: every neighbour is active).
+// SUB (row-subset form, yr_spmm_csr_subset): only the rows whose `row_active` flag is set are computed (the others
+// are left untouched).  A computed row goes through exactly the instructions of the full form: bit-identical.
 template <int D, bool ACCUM, bool SUB = false>
 __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int32_t* __restrict__ rowptr,
                                                           const int32_t* __restrict__ col,
@@ -87,9 +79,6 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int32_t* __restr
                                                           const float* __restrict__ X, float* __restrict__ Y,
                                                           int n, const int32_t* __restrict__ heavy, int n_heavy,
                                                           int heavy_t, const int32_t* __restrict__ row_active = nullptr,
-                                                          const int32_t* __restrict__ col_active = nullptr,
-                                                          const int32_t* __restrict__ row_perm = nullptr,
-                                                          int chunk = 0,
                                                           const int32_t* __restrict__ row_list = nullptr,
                                                           const int32_t* __restrict__ row_count = nullptr) {
   constexpr int LPR = D / 4, GPW = kWave / LPR;
@@ -100,109 +89,6 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const int32_t* __restr
     for (int h = blockIdx.x; h < n_heavy; h += kSpmmHeavyBlocks) {
       const int row = heavy[h];
       if (SUB && row_active && !row_active[row]) continue;          // workgroup-uniform
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (SUB && col_active)
-        spmm_accumulate<D, true>(col, val, X + 4 * l, rowptr[row], rowptr[row + 1], wave * GPW + grp,
-                                 kWavesPerBlock * GPW, acc, col_active);
-      else
-        spmm_accumulate<D>(col, val, X + 4 * l, rowptr[row], rowptr[row + 1], wave * GPW + grp, kWavesPerBlock * GPW, acc);
-#pragma unroll
-      for (int m = LPR; m < kWave; m <<= 1) {
-        acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
-        acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
-      }
-      if (grp == 0) s_acc[wave][l] = acc;
-      __syncthreads();
-      if (wave == 0 && grp == 0) {
-        float4 t = s_acc[0][l];
-#pragma unroll
-        for (int w = 1; w < kWavesPerBlock; ++w) {
-          const float4 o = s_acc[w][l];
-          t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
-        }
-        float* dst = Y + (int64_t)row * D + 4 * l;
-        if (ACCUM) {
-          const float4 old = ngcf_ld4(dst);
-          t.x += old.x; t.y += old.y; t.z += old.z; t.w += old.w;
-        }
-        *reinterpret_cast<float4*>(dst) = t;
-      }
-      __syncthreads();
-    }
-  } else {
-    // Clustered order (yr_spmm_csr_clustered): row_perm holds 8 chunks of `chunk` rows (-1 = padding), chunk x =
-    // the rows of graph cluster x; the workgroups with blockIdx % 8 == x — the ones the dispatcher places on XCD x —
-    // walk chunk x, so that the neighbour rows a cluster's rows share stay in that XCD's 4 MiB L2.  A placement
-    // hint only: any placement gives the same result.
-    const int lb = blockIdx.x - kSpmmHeavyBlocks;
-    const int nwaves = (row_perm ? (gridDim.x - kSpmmHeavyBlocks) / 8 : gridDim.x - kSpmmHeavyBlocks) * kWavesPerBlock;
-    const int first = (row_perm ? lb >> 3 : lb) * kWavesPerBlock + wave;
-    // row_list (with row_active): the light rows come from the set's LIST, so a set of a few rows costs a few waves
-    // instead of one early-exiting wave per graph row (20 us for 96 rows at Yelp2018 size)
-    const int limit = row_perm ? chunk : ((SUB && row_list) ? *row_count : n);
-    for (int it = first; it < limit; it += nwaves) {
-      int row = it;
-      if (row_perm) {
-        row = row_perm[(lb & 7) * chunk + it];
-        if (row < 0) continue;
-      }
-      if (SUB && row_list) row = row_list[it];
-      else if (SUB && row_active && !row_active[row]) continue;     // wave-uniform: one flag, then the next row
-      const int lo = rowptr[row], hi = rowptr[row + 1];
-      if (hi - lo > heavy_t) continue;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (SUB && col_active)
-        spmm_accumulate<D, true>(col, val, X + 4 * l, lo, hi, grp, GPW, acc, col_active);
-      else
-        spmm_accumulate<D>(col, val, X + 4 * l, lo, hi, grp, GPW, acc);
-#pragma unroll
-      for (int m = LPR; m < kWave; m <<= 1) {
-        acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
-        acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
-      }
-      if (grp == 0) {
-        float* dst = Y + (int64_t)row * D + 4 * l;
-        if (ACCUM) {
-          const float4 old = ngcf_ld4(dst);
-          acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
-        }
-        *reinterpret_cast<float4*>(dst) = acc;
-      }
-    }
-  }
-}
-
-// Tiled form (yr_spmm_csr_tiled): the row-per-wave kernel above pays three dependent round trips per row (row range
-// -> column / value pairs -> neighbour rows) and is bound by that chain times the rounds of waves, not by bytes
-// (PMC: a clustered row order cut the fabric bytes by 18 % and the time by nothing).  Here a workgroup owns a TILE of
-// consecutive rows whose non-zeros fit the LDS stage (host-made partition: <= kTileRows rows, <= kTileCap
-// non-zeros, long rows excluded): the tile's row ranges and ALL its column / value pairs arrive with two coalesced
-// round trips for the whole tile, then the waves take rows off an LDS counter and run a two-stage pipeline over
-// gather rounds — the gathers of round i + 1 (the same row's next 4 x 8 neighbours, or the next row's first) are
-// issued before round i is consumed, with the indices coming from LDS.
-constexpr int kTileRows = 32;
-constexpr int kTileCap = 2048;
-
-template <int D, bool ACCUM>
-__global__ __launch_bounds__(kBlock) void spmm_csr_tiled_kernel(const int32_t* __restrict__ rowptr,
-                                                                const int32_t* __restrict__ col,
-                                                                const float* __restrict__ val,
-                                                                const float* __restrict__ X, float* __restrict__ Y,
-                                                                const int32_t* __restrict__ heavy, int n_heavy,
-                                                                int heavy_t, const int32_t* __restrict__ tile_ptr,
-                                                                int n_tiles) {
-  constexpr int LPR = D / 4, GPW = kWave / LPR;
-  __shared__ float4 s_acc[kWavesPerBlock][LPR];
-  __shared__ int s_rp[kTileRows + 1];
-  __shared__ int s_lo[kTileRows + 1];
-  __shared__ int s_col[kTileCap];
-  __shared__ float s_val[kTileCap];
-  __shared__ int s_next;
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  const int grp = lane / LPR, l = lane % LPR;
-  if ((int)blockIdx.x < kSpmmHeavyBlocks) {
-    for (int h = blockIdx.x; h < n_heavy; h += kSpmmHeavyBlocks) {
-      const int row = heavy[h];
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       spmm_accumulate<D>(col, val, X + 4 * l, rowptr[row], rowptr[row + 1], wave * GPW + grp, kWavesPerBlock * GPW, acc);
 #pragma unroll
@@ -228,103 +114,34 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_tiled_kernel(const int32_t* _
       }
       __syncthreads();
     }
-    return;
-  }
-  const float* Xl = X + 4 * l;
-  for (int tile = blockIdx.x - kSpmmHeavyBlocks; tile < n_tiles; tile += gridDim.x - kSpmmHeavyBlocks) {
-    const int r0 = tile_ptr[tile], r1 = tile_ptr[tile + 1];
-    const int nr = r1 - r0;
-    if ((int)threadIdx.x <= nr) s_rp[threadIdx.x] = rowptr[r0 + threadIdx.x];
-    if (threadIdx.x == 0) s_next = kWavesPerBlock;
-    __syncthreads();
-    // stage the pairs of the tile's LIGHT rows back to back: s_lo[r] = where row r's pairs start in the stage (a
-    // long row, owned by the first workgroups, takes no room — the host's partition counts it as empty)
-    if (threadIdx.x == 0) {
-      int at = 0;
-      for (int r = 0; r < nr; ++r) {
-        s_lo[r] = at;
-        const int len = s_rp[r + 1] - s_rp[r];
-        if (len <= heavy_t) at += len;
+  } else {
+    const int lb = blockIdx.x - kSpmmHeavyBlocks;
+    const int nwaves = (gridDim.x - kSpmmHeavyBlocks) * kWavesPerBlock;
+    // row_list (with row_active): the light rows come from the set's LIST, so a set of a few rows costs a few waves
+    // instead of one early-exiting wave per graph row (20 us for 96 rows at Yelp2018 size)
+    const int limit = (SUB && row_list) ? *row_count : n;
+    for (int it = lb * kWavesPerBlock + wave; it < limit; it += nwaves) {
+      int row = it;
+      if (SUB && row_list) row = row_list[it];
+      else if (SUB && row_active && !row_active[row]) continue;     // wave-uniform: one flag, then the next row
+      const int lo = rowptr[row], hi = rowptr[row + 1];
+      if (hi - lo > heavy_t) continue;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      spmm_accumulate<D>(col, val, X + 4 * l, lo, hi, grp, GPW, acc);
+#pragma unroll
+      for (int m = LPR; m < kWave; m <<= 1) {
+        acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
+        acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
       }
-      s_lo[nr] = at;
-    }
-    __syncthreads();
-    if (s_lo[nr] == s_rp[nr] - s_rp[0]) {              // no long row in the tile: one flat coalesced copy
-      const int p0 = s_rp[0], np = s_lo[nr];
-      for (int i = threadIdx.x; i < np; i += kBlock) {
-        s_col[i] = col[p0 + i];
-        s_val[i] = val[p0 + i];
-      }
-    } else {
-      for (int r = 0; r < nr; ++r) {
-        const int len = s_rp[r + 1] - s_rp[r];
-        if (len > heavy_t) continue;
-        for (int i = threadIdx.x; i < len; i += kBlock) {
-          s_col[s_lo[r] + i] = col[s_rp[r] + i];
-          s_val[s_lo[r] + i] = val[s_rp[r] + i];
+      if (grp == 0) {
+        float* dst = Y + (int64_t)row * D + 4 * l;
+        if (ACCUM) {
+          const float4 old = ngcf_ld4(dst);
+          acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
         }
+        *reinterpret_cast<float4*>(dst) = acc;
       }
     }
-    __syncthreads();
-    // two-stage pipeline over (row, round) pairs; a round = GPW x kSpmmUnroll neighbours
-    float4 pr[kSpmmUnroll];
-    float pw[kSpmmUnroll];
-    int prow = -1;
-    bool plast = false;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto consume = [&]() {
-#pragma unroll
-      for (int q = 0; q < kSpmmUnroll; ++q) {
-        acc.x = fmaf(pw[q], pr[q].x, acc.x); acc.y = fmaf(pw[q], pr[q].y, acc.y);
-        acc.z = fmaf(pw[q], pr[q].z, acc.z); acc.w = fmaf(pw[q], pr[q].w, acc.w);
-      }
-      if (plast) {
-#pragma unroll
-        for (int m = LPR; m < kWave; m <<= 1) {
-          acc.x += __shfl_xor(acc.x, m, kWave); acc.y += __shfl_xor(acc.y, m, kWave);
-          acc.z += __shfl_xor(acc.z, m, kWave); acc.w += __shfl_xor(acc.w, m, kWave);
-        }
-        if (grp == 0) {
-          float* dst = Y + (int64_t)prow * D + 4 * l;
-          if (ACCUM) {
-            const float4 old = ngcf_ld4(dst);
-            acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
-          }
-          *reinterpret_cast<float4*>(dst) = acc;
-        }
-        acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    };
-    int lr = wave;                                     // local row; the following ones come off the LDS counter
-    while (lr < nr) {
-      const int len = s_rp[lr + 1] - s_rp[lr];
-      const int lo = s_lo[lr], hi = lo + len;
-      if (len <= heavy_t) {                            // (long rows belong to the first workgroups)
-        int base = lo;
-        do {
-          float4 nr4[kSpmmUnroll];
-          float nw[kSpmmUnroll];
-#pragma unroll
-          for (int q = 0; q < kSpmmUnroll; ++q) {
-            const int idx = base + grp + q * GPW;
-            const bool ok = idx < hi;
-            nw[q] = ok ? s_val[idx] : 0.0f;
-            nr4[q] = ok ? ngcf_ld4(Xl + (int64_t)s_col[idx] * D) : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-          if (prow >= 0) consume();
-#pragma unroll
-          for (int q = 0; q < kSpmmUnroll; ++q) { pr[q] = nr4[q]; pw[q] = nw[q]; }
-          base += GPW * kSpmmUnroll;
-          prow = r0 + lr;
-          plast = base >= hi;
-        } while (base < hi);
-      }
-      int nx = 0;
-      if (lane == 0) nx = atomicAdd(&s_next, 1);
-      lr = __shfl(nx, 0, kWave);
-    }
-    if (prow >= 0) consume();
-    __syncthreads();                                   // the stage is free for the next tile
   }
 }
 
@@ -948,8 +765,8 @@ extern "C" int yr_spmm_csr(const int32_t* rowptr, const int32_t* col, const floa
 extern "C" int yr_spmm_csr_subset(const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
                                   float* Y, int64_t n, int D, int accumulate, const int32_t* heavy_rows,
                                   int64_t n_heavy, int heavy_threshold, const int32_t* row_active,
-                                  const int32_t* col_active, const int32_t* row_list, const int32_t* row_count,
-                                  int64_t max_rows, void* stream) {
+                                  const int32_t* row_list, const int32_t* row_count, int64_t max_rows,
+                                  void* stream) {
   if (n < 0 || n > 0x7fffffff || n_heavy < 0 || n_heavy > n) return YR_ERR_BADARG;
   if (n == 0) return 0;
   if (!rowptr || !X || !Y || X == Y) return YR_ERR_BADARG;
@@ -964,36 +781,11 @@ extern "C" int yr_spmm_csr_subset(const int32_t* rowptr, const int32_t* col, con
   if (accumulate) {
     YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_csr_kernel<kD, true, true>), dim3(grid), dim3(kBlock), 0, s, rowptr,
                                            col, val, X, Y, (int)n, heavy_rows, (int)n_heavy, heavy_threshold,
-                                           row_active, col_active, nullptr, 0, row_list, row_count));
+                                           row_active, row_list, row_count));
   } else {
     YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_csr_kernel<kD, false, true>), dim3(grid), dim3(kBlock), 0, s, rowptr,
                                            col, val, X, Y, (int)n, heavy_rows, (int)n_heavy, heavy_threshold,
-                                           row_active, col_active, nullptr, 0, row_list, row_count));
-  }
-  return launch_status();
-}
-
-extern "C" int yr_spmm_csr_clustered(const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
-                                     float* Y, int64_t n, int D, int accumulate, const int32_t* heavy_rows,
-                                     int64_t n_heavy, int heavy_threshold, const int32_t* row_perm, int64_t chunk,
-                                     const int32_t* row_active, void* stream) {
-  if (n < 0 || n > 0x7fffffff || n_heavy < 0 || n_heavy > n || chunk < 0 || chunk > n) return YR_ERR_BADARG;
-  if (n == 0) return 0;
-  if (!rowptr || !X || !Y || X == Y || !row_perm || chunk * 8 < n) return YR_ERR_BADARG;
-  if (n_heavy > 0 && !heavy_rows) return YR_ERR_BADARG;
-  if (heavy_threshold <= 0 || n_heavy == 0) heavy_threshold = n_heavy > 0 ? 256 : 0x7fffffff;
-  int per = (int)((chunk + kWavesPerBlock - 1) / kWavesPerBlock);
-  if (per > 8192) per = 8192;
-  const int grid = kSpmmHeavyBlocks + 8 * per;
-  hipStream_t s = (hipStream_t)stream;
-  if (accumulate) {
-    YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_csr_kernel<kD, true, true>), dim3(grid), dim3(kBlock), 0, s, rowptr,
-                                           col, val, X, Y, (int)n, heavy_rows, (int)n_heavy, heavy_threshold,
-                                           row_active, nullptr, row_perm, (int)chunk));
-  } else {
-    YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_csr_kernel<kD, false, true>), dim3(grid), dim3(kBlock), 0, s, rowptr,
-                                           col, val, X, Y, (int)n, heavy_rows, (int)n_heavy, heavy_threshold,
-                                           row_active, nullptr, row_perm, (int)chunk));
+                                           row_active, row_list, row_count));
   }
   return launch_status();
 }
@@ -1044,27 +836,6 @@ extern "C" int yr_ngcf_frontier_expand(const int32_t* rowptr, const int32_t* col
   if (grid > 16384) grid = 16384;
   hipLaunchKernelGGL(ngcf_frontier_expand_kernel, dim3(grid), dim3(kBlock), 0, s, rowptr, col, rows_in, count_in, flags,
                      rows, count);
-  return launch_status();
-}
-
-extern "C" int yr_spmm_csr_tiled(const int32_t* rowptr, const int32_t* col, const float* val, const float* X, float* Y,
-                                int64_t n, int D, int accumulate, const int32_t* heavy_rows, int64_t n_heavy,
-                                int heavy_threshold, const int32_t* tile_ptr, int64_t n_tiles, void* stream) {
-  if (n < 0 || n > 0x7fffffff || n_heavy < 0 || n_heavy > n || n_tiles < 0 || n_tiles > n) return YR_ERR_BADARG;
-  if (n == 0) return 0;
-  if (!rowptr || !X || !Y || X == Y || !tile_ptr) return YR_ERR_BADARG;
-  if (n_heavy > 0 && !heavy_rows) return YR_ERR_BADARG;
-  if (heavy_threshold <= 0 || n_heavy == 0) heavy_threshold = n_heavy > 0 ? 256 : 0x7fffffff;
-  if (heavy_threshold > kTileCap) return YR_ERR_BADARG;       // a light row must fit the LDS stage
-  const int grid = kSpmmHeavyBlocks + (int)(n_tiles > 65536 ? 65536 : (n_tiles < 1 ? 1 : n_tiles));
-  hipStream_t s = (hipStream_t)stream;
-  if (accumulate) {
-    YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_csr_tiled_kernel<kD, true>), dim3(grid), dim3(kBlock), 0, s, rowptr, col,
-                                           val, X, Y, heavy_rows, (int)n_heavy, heavy_threshold, tile_ptr, (int)n_tiles));
-  } else {
-    YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((spmm_csr_tiled_kernel<kD, false>), dim3(grid), dim3(kBlock), 0, s, rowptr, col,
-                                           val, X, Y, heavy_rows, (int)n_heavy, heavy_threshold, tile_ptr, (int)n_tiles));
-  }
   return launch_status();
 }
 

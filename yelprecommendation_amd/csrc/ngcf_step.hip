@@ -198,7 +198,7 @@ extern "C" int yr_ngcf_bpr_step(const int32_t* rowptr, const int32_t* col, const
   for (int k = 0; k < K; ++k) {
     if (sub[k]) {
       YR_TRY(yr_spmm_csr_subset(rowptr, col, val, layer(k), Zk(k), n, D, 0, heavy_rows, n_heavy, heavy_threshold,
-                                flags(k), nullptr, rows(k), counts + k, max_rows[k], stream));
+                                flags(k), rows(k), counts + k, max_rows[k], stream));
       YR_TRY(yr_ngcf_dense_fwd_rows(layer(k), Zk(k), W1[k], W2[k], n, D, layer(k + 1), rows(k), counts + k,
                                     max_rows[k], stream));
     } else {
@@ -250,7 +250,7 @@ extern "C" int yr_ngcf_bpr_step(const int32_t* rowptr, const int32_t* col, const
       {
         const bool below = k > 0 && sub[k - 1];
         YR_TRY(yr_spmm_csr_subset(rowptr, col, val, dZ, dlayer(k), n, D, 1, heavy_rows, n_heavy, heavy_threshold,
-                                  below ? flags(k - 1) : nullptr, nullptr, below ? rows(k - 1) : nullptr,
+                                  below ? flags(k - 1) : nullptr, below ? rows(k - 1) : nullptr,
                                   below ? counts + k - 1 : nullptr, below ? max_rows[k - 1] : 0, stream));
       }
     } else {

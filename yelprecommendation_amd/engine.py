@@ -293,22 +293,21 @@ def ngcf_frontier_expand(graph, rows, max_rows=None, push=False):
     return out
 
 
-def spmm_csr_subset(graph, X, out, row_active=None, col_active=None, accumulate=False, rows=None):
-    """:func:`spmm_csr` on the rows flagged in ``row_active`` (None: all) and, with ``col_active``, over the
-    flagged neighbours only; other rows of ``out`` are left as they are.  ``rows`` (NGCFRowSet, instead of
-    ``row_active``): the same with the set's list driving the launch (cheap for small sets)."""
+def spmm_csr_subset(graph, X, out, row_active=None, accumulate=False, rows=None):
+    """:func:`spmm_csr` on the rows flagged in ``row_active`` (int32 flags; None: all); other rows of ``out`` are left
+    as they are.  ``rows`` (NGCFRowSet, instead of ``row_active``): the same with the set's list driving the launch
+    (cheap for small sets)."""
     if rows is not None:
         row_active = rows.flags
     lib = _lib.load()
     n, d = X.shape
     if n != graph.n or out.shape != X.shape:
         raise EngineError(f"X / out must be [{graph.n}, D]")
-    u8 = torch.int32                                   # the row sets' flags
     check(lib.yr_spmm_csr_subset(_dev(graph.rowptr, torch.int32, "rowptr"), _dev(graph.col, torch.int32, "col"),
                                  _dev(graph.val, torch.float32, "val"), _dev(X, torch.float32, "X"),
                                  _dev(out, torch.float32, "Y"), n, d, 1 if accumulate else 0,
                                  _opt(graph.heavy_rows, torch.int32, "heavy_rows"), graph.n_heavy, graph.heavy_threshold,
-                                 _opt(row_active, u8, "row_active"), _opt(col_active, u8, "col_active"),
+                                 _opt(row_active, torch.int32, "row_active"),
                                  None if rows is None else rows.rows.data_ptr(),
                                  None if rows is None else rows.count.data_ptr(), 0 if rows is None else rows.max_rows,
                                  _stream()),
@@ -327,47 +326,6 @@ def spmm_csr_push_rows(graph, X, out, rows):
                                     _dev(graph.val, torch.float32, "val"), _dev(X, torch.float32, "X"),
                                     _dev(out, torch.float32, "Y"), n, d, rows.rows.data_ptr(), rows.count.data_ptr(),
                                     rows.max_rows, _stream()), "yr_spmm_csr_push_rows")
-    return out
-
-
-def spmm_csr_tiled(graph, X, out=None, accumulate=False):
-    """:func:`spmm_csr` in the tiled form (yr_spmm_csr_tiled): a workgroup per tile of consecutive rows, index data
-    staged in LDS, gathers of consecutive rows pipelined."""
-    lib = _lib.load()
-    n, d = X.shape
-    if n != graph.n:
-        raise EngineError(f"X has {n} rows, the graph {graph.n}")
-    if out is None:
-        if accumulate:
-            raise EngineError("accumulate needs an output buffer")
-        out = torch.empty_like(X)
-    tiles = graph.tiles()
-    check(lib.yr_spmm_csr_tiled(_dev(graph.rowptr, torch.int32, "rowptr"), _dev(graph.col, torch.int32, "col"),
-                                _dev(graph.val, torch.float32, "val"), _dev(X, torch.float32, "X"),
-                                _dev(out, torch.float32, "Y"), n, d, 1 if accumulate else 0,
-                                _opt(graph.heavy_rows, torch.int32, "heavy_rows"), graph.n_heavy, graph.heavy_threshold,
-                                _dev(tiles, torch.int32, "tile_ptr"), tiles.numel() - 1, _stream()), "yr_spmm_csr_tiled")
-    return out
-
-
-def spmm_csr_clustered(graph, X, row_perm, chunk, out=None, accumulate=False, row_active=None):
-    """:func:`spmm_csr` with the rows visited cluster by cluster, one cluster per XCD (``graph.cluster_order``)."""
-    lib = _lib.load()
-    n, d = X.shape
-    if n != graph.n:
-        raise EngineError(f"X has {n} rows, the graph {graph.n}")
-    if out is None:
-        if accumulate:
-            raise EngineError("accumulate needs an output buffer")
-        out = torch.empty_like(X)
-    if row_perm.numel() != 8 * chunk:
-        raise EngineError("row_perm must hold 8 chunks")
-    check(lib.yr_spmm_csr_clustered(_dev(graph.rowptr, torch.int32, "rowptr"), _dev(graph.col, torch.int32, "col"),
-                                    _dev(graph.val, torch.float32, "val"), _dev(X, torch.float32, "X"),
-                                    _dev(out, torch.float32, "Y"), n, d, 1 if accumulate else 0,
-                                    _opt(graph.heavy_rows, torch.int32, "heavy_rows"), graph.n_heavy,
-                                    graph.heavy_threshold, _dev(row_perm, torch.int32, "row_perm"), int(chunk),
-                                    _opt(row_active, torch.int32, "row_active"), _stream()), "yr_spmm_csr_clustered")
     return out
 
 

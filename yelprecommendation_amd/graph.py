@@ -37,77 +37,6 @@ class LaplacianCSR:
         order = np.concatenate([np.argsort(-deg[:split], kind="stable"), split + np.argsort(-deg[split:], kind="stable")])
         self.row_order = torch.from_numpy(order.astype(np.int32)).to(device)
 
-    def tiles(self, max_rows=32, max_nnz=2048):
-        """int32 tile_ptr [n_tiles + 1] on the device for yr_spmm_csr_tiled: consecutive rows cut greedily so that a
-        tile has at most ``max_rows`` rows and ``max_nnz`` non-zeros (rows longer than the heavy threshold count as
-        empty: the kernel's first workgroups own them)."""
-        cached = getattr(self, "_tiles", None)
-        if cached is not None and cached[0] == (max_rows, max_nnz):
-            return cached[1]
-        deg = np.diff(self.rowptr.cpu().numpy().astype(np.int64))
-        deg = np.where(deg > self.heavy_threshold, 0, deg)
-        if deg.size and deg.max() > max_nnz:
-            raise ValueError("a light row does not fit a tile")
-        cum = np.concatenate([[0], np.cumsum(deg)])
-        cuts, r = [0], 0
-        n = self.n
-        while r < n:
-            hi = min(n, r + max_rows)
-            # the furthest end <= hi whose non-zeros fit
-            end = int(np.searchsorted(cum, cum[r] + max_nnz, side="right")) - 1
-            r = max(r + 1, min(hi, end))
-            cuts.append(r)
-        out = torch.from_numpy(np.asarray(cuts, dtype=np.int32)).to(self.rowptr.device)
-        self._tiles = ((max_rows, max_nnz), out)
-        return out
-
-    def cluster_order(self, split, clusters=8, iters=6, seed=0):
-        """(row_perm int32[clusters * chunk] on the device, chunk) for yr_spmm_csr_clustered: a balanced
-        co-clustering of the bipartite graph (users = nodes below ``split``).  Alternating label propagation — a
-        user goes to the cluster most of its items are in, an item to the cluster most of its users are in, every
-        cluster capped at 1 / clusters of each side (most decided rows first) — a few bincount passes over the
-        edges at load time.  Chunk x lists the users, then the items of cluster x, padded with -1."""
-        key = (int(split), int(clusters), int(iters), int(seed))
-        cached = getattr(self, "_cluster_cache", None)
-        if cached is not None and cached[0] == key:
-            return cached[1], cached[2]
-        rp = self.rowptr.cpu().numpy().astype(np.int64)
-        col = self.col.cpu().numpy().astype(np.int64)
-        n, nu = self.n, int(split)
-        ni, C = n - nu, int(clusters)
-        rows = np.repeat(np.arange(n), np.diff(rp))
-        um = rows < nu                                             # the edges user -> item (the other half mirrors them)
-        eu, ei = rows[um], col[um] - nu
-        if ((ei < 0) | (ei >= ni)).any():
-            raise ValueError("cluster_order: the graph is not bipartite at this split")
-
-        def assign(score, cap):
-            pref = np.argsort(-score, axis=1, kind="stable")
-            part = np.sort(score, axis=1)
-            order = np.argsort(-(part[:, -1] - part[:, -2]), kind="stable") if C > 1 else np.arange(score.shape[0])
-            out, load = np.empty(score.shape[0], np.int64), [0] * C
-            for r in order.tolist():
-                for c in pref[r].tolist():
-                    if load[c] < cap:
-                        out[r], load[c] = c, load[c] + 1
-                        break
-            return out
-
-        ci = np.random.RandomState(seed).randint(0, C, ni)
-        cu = np.zeros(nu, np.int64)
-        for _ in range(max(1, iters)):
-            cu = assign(np.bincount(eu * C + ci[ei], minlength=nu * C).reshape(nu, C).astype(np.float64), -(-nu // C))
-            ci = assign(np.bincount(ei * C + cu[eu], minlength=ni * C).reshape(ni, C).astype(np.float64), -(-ni // C))
-        self.cluster_intra_fraction = float((cu[eu] == ci[ei]).mean()) if eu.size else 1.0
-        lists = [np.concatenate([np.flatnonzero(cu == c), nu + np.flatnonzero(ci == c)]) for c in range(C)]
-        chunk = max(len(l) for l in lists)
-        perm = np.full((C, chunk), -1, np.int32)
-        for c, l in enumerate(lists):
-            perm[c, :len(l)] = l
-        out = torch.from_numpy(perm.reshape(-1)).to(self.rowptr.device)
-        self._cluster_cache = (key, out, int(chunk))
-        return out, int(chunk)
-
     @classmethod
     def from_scipy(cls, mat, device, heavy_threshold=HEAVY_THRESHOLD, split=None):
         mat = mat.tocsr()
