@@ -122,6 +122,44 @@ def test_deterministic_mode_with_oversize_tile_segments(device, d, nu, ni, B):
         torch.testing.assert_close(a, b, rtol=2e-3, atol=tol)
 
 
+@pytest.mark.parametrize("B", [1 << 16, 1 << 19])
+def test_oversize_item_buckets_are_shared_between_workgroups(device, B):
+    """A few items taking several per cent of a batch (here: 8 % of the positives on ONE bucket of 16 items, 3 % on a
+    second, one item alone 2 %) at Yelp2018 shape.  The item pass shares such a bucket's tiles between its owner and
+    helper workgroups — each leaves its partial sums in a scratch slot, the last to arrive adds them in part order
+    and applies Adam (round 2 walked the bucket with ONE workgroup: 1.3 ms at 2^20 triplets, now 0.26 ms).  The
+    result equals the atomic form's to summation order, two deterministic runs are bit-identical, and the loss is
+    the same in all forms."""
+    from yelprecommendation_amd.bpr_step import BPRMFStep
+    g = torch.Generator(device=device).manual_seed(B)
+    nu, ni, d = 31668, 38048, 64
+    U = (torch.rand(nu, d, generator=g, device=device) - 0.5) * 0.2
+    I = (torch.rand(ni, d, generator=g, device=device) - 0.5) * 0.2
+    batches = []
+    for _ in range(2):
+        u = torch.randint(0, nu, (B,), generator=g, device=device)
+        p = torch.randint(0, ni, (B,), generator=g, device=device)
+        r = torch.rand(B, generator=g, device=device)
+        p = torch.where(r < 0.08, torch.randint(4000, 4016, (B,), generator=g, device=device), p)          # one bucket
+        p = torch.where((r >= 0.08) & (r < 0.11), torch.randint(20000, 20016, (B,), generator=g, device=device), p)
+        p = torch.where((r >= 0.11) & (r < 0.13), torch.full_like(p, 77), p)                               # one item
+        batches.append((u, p.contiguous(), torch.randint(0, ni, (B,), generator=g, device=device)))
+    out = {}
+    for name, kw in (("pull", dict(impl="pull")), ("det", dict(impl="pull", deterministic=True)),
+                     ("det2", dict(impl="pull", deterministic=True)), ("atomic", dict(impl="atomic"))):
+        st = BPRMFStep(U.clone(), I.clone(), lr=1e-3, **kw)
+        for k in range(4):
+            st.step(*batches[k % 2])
+        st.check()
+        out[name] = [x.clone() for x in (st.U, st.I, st.mI, st.vI)] + [st.epoch_loss()]
+    for a, b in zip(out["det"], out["det2"]):
+        assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+    for other in ("pull", "det"):
+        for a, b, tol in zip(out[other][:4], out["atomic"][:4], (2e-5, 2e-5, 2e-6, 1e-8)):
+            torch.testing.assert_close(a, b, rtol=2e-3, atol=tol)
+        assert abs(out[other][4] - out["atomic"][4]) <= 1e-5 * abs(out["atomic"][4])
+
+
 def test_pull_step_empty_batch_still_decays_state(device):
     """Dense-Adam semantics: a step with no triplets still moves every row (m/v decay)."""
     from yelprecommendation_amd.bpr_step import BPRMFStep

@@ -63,6 +63,19 @@ constexpr int kMaxOwnerGrid = 4096;
 #define YR_HEAVY_ROW 96
 #endif
 constexpr int kHeavyRow = YR_HEAVY_ROW;          // records per row and chunk from which all four waves share the row
+// Oversize item buckets (a few rows that take several per cent of a batch: one workgroup would walk them chunk after
+// chunk, 1.3 ms at 2^20 triplets): the bucket's tiles are shared out between `parts` workgroups — the owner and
+// parts - 1 helpers —, each leaves the partial sums of its tile range in a scratch slot, the LAST to arrive adds
+// the slots in part order (a fixed order: the deterministic mode survives) and applies Adam.
+#ifndef YR_SPLIT_MIN
+#define YR_SPLIT_MIN 2048
+#endif
+constexpr int kSplitMin = YR_SPLIT_MIN;          // records of a bucket from which it is split
+constexpr int kSplitTarget = 1024;               // records per part (one chunk of the item pass)
+constexpr int kMaxParts = 64;
+constexpr int kMaxTasks = 512;                   // helper workgroups at the front of the item pass's grid
+constexpr int kMaxSlots = 1024;                  // scratch slots of 1024 floats (one bucket's rows)
+constexpr int kBuildLanes = 4;                   // lanes that share one item bucket in the sizing workgroups of the USER pass
 #ifndef YR_OWNER_WAVES
 #define YR_OWNER_WAVES 8              // waves per SIMD the owner pass is compiled for (8 workgroups per CU: <= 64 VGPRs)
 #endif
@@ -123,12 +136,14 @@ __global__ __launch_bounds__(kPartThreads) void tile_partition_kernel(
     const int64_t* __restrict__ user, const int64_t* __restrict__ pos, const int64_t* __restrict__ neg, int64_t B,
     int64_t nU, int64_t nI, int shiftU, int shiftI, int nbU, int nbI, int32_t* __restrict__ offU,
     int32_t* __restrict__ offI,
-    int4* __restrict__ rec, int2* __restrict__ occ, int32_t* __restrict__ err_flag, int stage_off) {
+    int4* __restrict__ rec, int2* __restrict__ occ, int32_t* __restrict__ err_flag, int stage_off,
+    int32_t* __restrict__ split_counters) {
   extern __shared__ int32_t s_cnt[];            // [nb + 1] bucket counters, then (16-byte aligned) the staged tile
   __shared__ int s_wave[kPartThreads / kWave];
   int4* s_stage = reinterpret_cast<int4*>(s_cnt + stage_off);   // TILE records of 16 B, or 2 TILE of 8 B
   constexpr int TILE = kPartThreads * PT;
   const int side = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+  if (side == 0 && tile == 0 && tid < 2) split_counters[tid] = 0;     // {tasks, scratch slots} of this batch
   const int nb = side ? nbI : nbU;
   const int shift = side ? shiftI : shiftU;
   const int rmask = (1 << shift) - 1;
@@ -251,7 +266,71 @@ struct OwnerArgs {
   int heavy_t;               // rows with more records in a chunk are walked by all four waves
   float inv_batch;
   AdamC adam;
+  // oversize item buckets (see kSplitMin): `split` = the bookkeeping block of the workspace — {tasks, slots}
+  // counters (16 B), then parts[nbI], slot[nbI], arrive[nbI] (each padded to 16 B), then the task list.
+  // Item pass: the first helper_blocks workgroups are helpers (task j); parts[k] > 1 marks a split bucket whose
+  // parts leave their sums in scratch slot slot[k] + part.  User pass: its last build_blocks workgroups fill the
+  // block for the item pass that follows, from the item-side offsets b_off [T][b_nb + 1].
+  // (One pointer instead of seven: the kernel arguments live in scalar registers, and the item pass has none to spare.)
+  char* split;
+  float* scratch;
+  const int32_t* b_off;
+  int helper_blocks, build_blocks, b_nb;
 };
+
+// the pieces of the `split` block
+__host__ __device__ __forceinline__ size_t split_per(int nbI) { return ((size_t)nbI * 4 + 15) & ~(size_t)15; }
+__device__ __forceinline__ int32_t* split_counters(char* b) { return (int32_t*)b; }
+__device__ __forceinline__ int32_t* split_parts(char* b) { return (int32_t*)(b + 16); }
+__device__ __forceinline__ int32_t* split_slot(char* b, int nbI) { return (int32_t*)(b + 16 + split_per(nbI)); }
+__device__ __forceinline__ int32_t* split_arrive(char* b, int nbI) { return (int32_t*)(b + 16 + 2 * split_per(nbI)); }
+__device__ __forceinline__ int4* split_tasks(char* b, int nbI) { return (int4*)(b + 16 + 3 * split_per(nbI)); }
+
+// Sizing of the item buckets (first workgroups of the user pass): kBuildLanes lanes per bucket add up its records
+// over the tiles (lane j takes tiles j, j + kBuildLanes, ...), the group's first lane decides the parts; split
+// buckets get scratch slots and helper tasks.
+__device__ __forceinline__ void build_splits(const OwnerArgs& a, int builder) {
+  const int k = (builder * kBlock + (int)threadIdx.x) / kBuildLanes, j = threadIdx.x % kBuildLanes;
+  int total = 0;
+  if (k < a.b_nb) {
+    int t = j;
+    const int64_t pitch = a.b_nb + 1;
+    for (; t + 3 * kBuildLanes < a.T; t += 4 * kBuildLanes) {           // four tiles in flight per lane
+      const int32_t* o0 = a.b_off + (int64_t)t * pitch + k;
+      const int32_t* o1 = o0 + kBuildLanes * pitch;
+      const int32_t* o2 = o1 + kBuildLanes * pitch;
+      const int32_t* o3 = o2 + kBuildLanes * pitch;
+      const int a0 = o0[0], b0 = o0[1], a1 = o1[0], b1 = o1[1], a2 = o2[0], b2 = o2[1], a3 = o3[0], b3 = o3[1];
+      total += ((b0 - a0) + (b1 - a1)) + ((b2 - a2) + (b3 - a3));
+    }
+    for (; t < a.T; t += kBuildLanes) {
+      const int32_t* orow = a.b_off + (int64_t)t * (a.b_nb + 1) + k;
+      total += orow[1] - orow[0];
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < kBuildLanes; m <<= 1) total += __shfl_xor(total, m, kWave);
+  if (k >= a.b_nb || j != 0) return;
+  int parts = 1;
+  if (total >= kSplitMin) {
+    parts = (total + kSplitTarget - 1) / kSplitTarget;
+    parts = min(parts, min(kMaxParts, a.T));
+  }
+  int slot = 0;
+  if (parts > 1) {
+    slot = atomicAdd(split_counters(a.split) + 1, parts);
+    const int first = atomicAdd(split_counters(a.split), parts - 1);
+    // no room left (more than kMaxSlots / kMaxTasks parts in one batch): the bucket stays whole and the task
+    // entries it took are marked void
+    const bool fits = slot + parts <= kMaxSlots && first + parts - 1 <= kMaxTasks;
+    for (int q = 1; q < parts; ++q)
+      if (first + q - 1 < kMaxTasks) split_tasks(a.split, a.b_nb)[first + q - 1] = make_int4(fits ? k : -1, q, 0, 0);
+    if (!fits) parts = 1;
+  }
+  split_parts(a.split)[k] = parts;
+  split_slot(a.split, a.b_nb)[k] = slot;
+  split_arrive(a.split, a.b_nb)[k] = 0;
+}
 
 // sum a float4 over the lane groups of a wave (lanes with equal l)
 template <int LPR>
@@ -408,14 +487,41 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
   const bool finisher = grp < RPW;                // lane groups that finish a row (all of them unless RPW < GPW)
   const int row_l = wave * RPW + (finisher ? grp : 0);
   float loss = 0.0f;
+  __shared__ int s_last;
+  if (USER && (int)blockIdx.x < a.build_blocks) {
+    // the user pass's first workgroups size the item buckets for the item pass that follows (no launch of its own;
+    // first, so that they are done long before the owners)
+    build_splits(a, blockIdx.x);
+    return;
+  }
+  // item pass: the first hb workgroups are helpers of split buckets; user pass: the first hb are the sizing ones
+  const int hb = USER ? a.build_blocks : a.helper_blocks;
+  const bool helper = !USER && (int)blockIdx.x < hb;
+  const int owners = (int)gridDim.x - hb;
 #ifdef YR_STAMPS
   bool first_bucket = true;
 #endif
   YR_STAMP(0);
 
-  for (int ks = a.bucket_begin + blockIdx.x; ks < a.bucket_end; ks += gridDim.x) {
+  for (int ks = helper ? (int)blockIdx.x : a.bucket_begin + (int)blockIdx.x - hb;
+       helper ? ks == (int)blockIdx.x : ks < a.bucket_end; ks += owners) {
     // workgroups start in slot order: the caller may put heavy buckets first (wave-uniform: kept in a scalar register)
-    const int k = __builtin_amdgcn_readfirstlane(a.order ? a.order[ks] : ks);
+    int k, part = 0, parts = 1;
+    if (helper) {
+      if (ks >= min(split_counters(a.split)[0], kMaxTasks)) break;
+      const int4 task = split_tasks(a.split, a.nb)[ks];
+      k = __builtin_amdgcn_readfirstlane(task.x);
+      part = __builtin_amdgcn_readfirstlane(task.y);
+      if (k < a.bucket_begin || k >= a.bucket_end) break;       // void task, or a bucket of another item chunk
+    } else {
+      k = __builtin_amdgcn_readfirstlane(a.order ? a.order[ks] : ks);
+    }
+    if (!USER && a.split) parts = __builtin_amdgcn_readfirstlane(split_parts(a.split)[k]);
+    // this workgroup's share of the bucket: the tiles [t_begin, t_end)
+    // (an integer division runs on the vector unit: the results are moved back to scalar registers, or they would
+    // cost the item pass two VGPRs it does not have — 12 B of scratch per lane, caught by scripts/kernel_resources.py)
+    const int t_begin = __builtin_amdgcn_readfirstlane(a.T * part / parts);
+    const int t_end = __builtin_amdgcn_readfirstlane(a.T * (part + 1) / parts);
     const int row_f = k * R + row_l;
     const bool valid_f = finisher && row_f < a.rows;
     const uint32_t o_f = (uint32_t)(row_f * D + 4 * l);
@@ -424,8 +530,8 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
     RowSums<LPR, GPW> sums;
     sums.clear();
 
-    for (int tg0 = 0; tg0 < a.T; tg0 += kTileGroup) {
-      const int nt = min(kTileGroup, a.T - tg0);
+    for (int tg0 = t_begin; tg0 < t_end; tg0 += kTileGroup) {
+      const int nt = min(kTileGroup, t_end - tg0);
       // segment descriptors of bucket k in tiles [tg0, tg0 + nt), exclusive scan of their lengths
       int len = 0;
       if (tid < nt) {
@@ -655,7 +761,32 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
     }
 
     YR_STAMP(3);
-    const float4 acc = sums.finish(grp);
+    float4 acc = sums.finish(grp);
+    if (!USER && parts > 1) {
+      // a split bucket: leave this part's sums in its scratch slot; the last part to arrive adds the slots in part
+      // order and goes on to the update, the others are done with the bucket
+      // (the base goes through an empty asm: otherwise scratch + this lane's offset is hoisted out of the bucket
+      // loop into a VGPR pair the item pass does not have — it was spilled to scratch memory)
+      float* sbase = a.scratch;
+      asm volatile("" : "+s"(sbase));
+      float* slots = sbase + (int64_t)split_slot(a.split, a.nb)[k] * (R * D);
+      if (finisher) st4(slots + (int64_t)part * (R * D) + row_l * D + 4 * l, acc);
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) s_last = atomicAdd(split_arrive(a.split, a.nb) + k, 1) == parts - 1;
+      __syncthreads();
+      const bool last = s_last != 0;
+      __syncthreads();                           // s_last may be rewritten by the next bucket
+      if (!last) continue;
+      __threadfence();
+      acc = zero4();
+      if (finisher) {
+        for (int q = 0; q < parts; ++q) {
+          const float4 t = ld4(slots + (int64_t)q * (R * D) + row_l * D + 4 * l);
+          acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+      }
+    }
     if (valid_f) {
       if (FUSE_ADAM) {
         float4 own = USER ? s_own[row_l * LPR + l] : ld4o(a.own_old, o_f);
@@ -681,10 +812,10 @@ __global__ __launch_bounds__(kBlock, YR_OWNER_WAVES) void owner_pass_kernel(Owne
 
   if (USER) {
     const float total = block_sum(loss, s_red);
-    if (tid == 0) a.loss_partials[blockIdx.x] = total;
-    if (blockIdx.x == 0)                          // slots no workgroup owns
-      for (int i = gridDim.x + tid; i < YR_LOSS_PARTIALS; i += kBlock) a.loss_partials[i] = 0.0f;
-  } else if (a.finalize && blockIdx.x == 0) {
+    if (tid == 0) a.loss_partials[(int)blockIdx.x - hb] = total;
+    if ((int)blockIdx.x == hb)                    // slots no workgroup owns
+      for (int i = owners + tid; i < YR_LOSS_PARTIALS; i += kBlock) a.loss_partials[i] = 0.0f;
+  } else if (a.finalize && (int)blockIdx.x == hb) {
     // the user pass (previous launch) left one partial per workgroup: fixed-order sum -> step loss
     float s = 0.0f;
     for (int i = tid; i < YR_LOSS_PARTIALS; i += kBlock) s += a.loss_partials[i];
@@ -713,12 +844,14 @@ __global__ __launch_bounds__(kBlock) void pull_loss_finalize_kernel(const float*
 
 // --------------------------------------------------------------------------- host side
 // How a batch of B triplets is cut into tiles, and the workspace carve-up (all 16-byte aligned).
+inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 struct PullPlan {
   int pt, tile, T, shiftU, shiftI, narrow_users, nbU, nbI;
-  size_t o_offU, o_offI, o_rec, o_occ, o_coeff, bytes;
+  size_t o_offU, o_offI, o_rec, o_occ, o_coeff, o_split, o_scratch, bytes;
 };
-
-inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+// split bookkeeping inside the workspace: {tasks, slots} counters (16 B), parts / slot / arrivals per item bucket,
+// the task list; then the scratch slots
+inline size_t split_bytes(int nbI) { return 16 + (size_t)3 * align16((size_t)nbI * 4) + (size_t)kMaxTasks * sizeof(int4); }
 
 // tiles of 4096 triplets, halved while there would be fewer than kMinTiles of them (the partition launch
 // and the owners' segment runs both want tiles that are neither too few nor too small)
@@ -750,6 +883,8 @@ inline PullPlan make_plan(int64_t B, int64_t nU, int64_t nI, int D, bool upper_b
   p.o_rec = o; o += align16((size_t)slots * sizeof(int4));
   p.o_occ = o; o += align16((size_t)slots * 2 * sizeof(int2));
   p.o_coeff = o; o += align16((size_t)(B > 0 ? B : 1) * 4);
+  p.o_split = o; o += align16(split_bytes(p.nbI));
+  p.o_scratch = o; o += (size_t)kMaxSlots * 1024 * 4;
   p.bytes = o;
   return p;
 }
@@ -814,7 +949,8 @@ extern "C" int yr_bpr_mf_pull_index(const int64_t* user, const int64_t* pos, con
       raised = true;                                                                                             \
     }                                                                                                            \
     hipLaunchKernelGGL((tile_partition_kernel<PT>), grid, dim3(kPartThreads), lds, s, user, pos, neg, B, num_users, \
-                       num_items, p.shiftU, p.shiftI, p.nbU, p.nbI, offU, offI, rec, occ, err_flag, stage_off);  \
+                       num_items, p.shiftU, p.shiftI, p.nbU, p.nbI, offU, offI, rec, occ, err_flag, stage_off,   \
+                       (int32_t*)(w + p.o_split));                                                              \
   } break
   switch (p.pt) {
     YR_PART_CASE(1);
@@ -860,7 +996,11 @@ static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU
     ua.bucket_begin = 0; ua.bucket_end = p.nbU;
     ua.order = nullptr;
     ua.heavy_t = kHeavyRow; ua.inv_batch = inv_batch; ua.adam = adam;
-    const int gu = p.nbU < YR_LOSS_PARTIALS ? p.nbU : YR_LOSS_PARTIALS;   // one loss-partial slot per workgroup
+    // the last kSplitBuilders workgroups size the item buckets (oversize ones are shared out in the item pass)
+    ua.build_blocks = (p.nbI * kBuildLanes + kBlock - 1) / kBlock;
+    ua.b_off = (const int32_t*)(w + p.o_offI); ua.b_nb = p.nbI;
+    ua.split = w + p.o_split;
+    const int gu = (p.nbU < YR_LOSS_PARTIALS ? p.nbU : YR_LOSS_PARTIALS) + ua.build_blocks;   // one loss-partial slot per owner
     if (p.narrow_users && deterministic)
       hipLaunchKernelGGL((owner_pass_kernel<D, true, true, true, 1>), dim3(gu), dim3(kBlock), 0, s, ua);
     else if (p.narrow_users)
@@ -883,8 +1023,12 @@ static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU
     // a start order is a permutation of ALL item buckets: used when the call covers all of them
     ia.order = (item_order && ia.bucket_begin == 0 && ia.bucket_end == p.nbI) ? item_order : nullptr;
     ia.heavy_t = kHeavyRow; ia.inv_batch = inv_batch; ia.adam = adam;
+    ia.helper_blocks = kMaxTasks;
+    ia.split = w + p.o_split;
+    ia.scratch = (float*)(w + p.o_scratch);
     int gi = ia.bucket_end - ia.bucket_begin;
     if (gi > kMaxOwnerGrid) gi = kMaxOwnerGrid;
+    gi += kMaxTasks;                              // helpers first: they start before the owners
     if (gradI_out && deterministic)
       hipLaunchKernelGGL((owner_pass_kernel<D, false, false, true>), dim3(gi), dim3(kBlock), 0, s, ia);
     else if (gradI_out)
