@@ -40,7 +40,7 @@ BUDGETS = [
 # __launch_bounds__ and spill a few words (measured cost in profiles/r02_deterministic_mode_cost.txt) — capped here
 # so that it cannot grow unnoticed.
 SCRATCH_ALLOWED = {
-    r"void yr::owner_pass_kernel<(16|32|64|128), (true|false), (true|false), true, [01]>": 48,   # deterministic order
+    r"void yr::owner_pass_kernel<(16|32|64|128), (true|false), (true|false), true, [01]>": 64,   # deterministic order
     r"void yr::owner_pass_kernel<(16|32|128), (true|false), (true|false), false, [01]>": 16,
     r"void yr::topk_masked_kernel<32, 1024>": 160,       # unfused fallback for 16 < k <= 32 (a 32-entry list per thread)
 }
