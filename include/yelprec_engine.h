@@ -435,6 +435,21 @@ int yr_cdae_train_lists(const int64_t *ptr, const int64_t *idx, const int64_t *p
                         uint64_t drop_seed, double p, int32_t *cols, float *vals, int32_t *count,
                         int32_t *loss_cols, float *loss_targets, int32_t *loss_count,
                         int32_t *err_flag, void *stream);
+/* yr_cdae_train_lists_batched: the lists of SEVERAL batches in one launch — row r is row r % batch_rows of batch
+ *   r / batch_rows and takes neg_seeds / drop_seeds [r / batch_rows] (device arrays): exactly the lists one
+ *   yr_cdae_train_lists call per batch gives, B = all rows.  yr_cdae_loss_finalize_batched: after ONE
+ *   yr_cdae_sampled_decode over those rows (dz = dWo = dbo = NULL), *loss_accum += sum over the batches of
+ *   (sum of the batch's loss partials / its position count) — CDAETrainer.validate's `valid_loss += loss`
+ *   (trainers/cdae_trainer.py:56-88) for all those batches; splits = yr_cdae_sampled_decode_splits(B) of that
+ *   launch, means: float[number of batches] scratch, arrive: int32[1], zero on entry and on exit. */
+int yr_cdae_train_lists_batched(const int64_t *ptr, const int64_t *idx, const int64_t *ptr2, const int64_t *idx2,
+                                const int64_t *users, int64_t B, int64_t num_users, int64_t I, int neg_times,
+                                const uint64_t *neg_seeds, const uint64_t *drop_seeds, int64_t batch_rows, double p,
+                                int32_t *cols, float *vals, int32_t *count, int32_t *loss_cols, float *loss_targets,
+                                int32_t *loss_count, int32_t *err_flag, void *stream);
+int yr_cdae_loss_finalize_batched(const float *partial_loss, int splits, const int32_t *loss_count, int64_t rows,
+                                  int64_t batch_rows, float *means, int32_t *arrive, double *loss_accum,
+                                  void *stream);
 int yr_cdae_sampled_decode_splits(int64_t B);
 /* yr_cdae_sampled_decode with dz = dWo = dbo = NULL computes the loss partials and the count only (validation);
  * yr_cdae_loss_finalize then gives stats[0] = sum(partials) / count (fixed order), stats[1] = count,

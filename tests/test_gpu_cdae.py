@@ -679,6 +679,14 @@ def test_list_route_of_validate_and_evaluate_equals_dense_route(device, tmp_path
         if mode == "valid":
             got, want = trainer.validate(as_lists), trainer.validate(dense)
             np.testing.assert_allclose(got[0], want[0], rtol=1e-5)
+            # as_lists went through CDAEBatchLoader.super_batches (8 batches per launch, cfg.eval_batch_group); one
+            # launch set per batch gives the same lists (same seeds per batch), the same per-batch losses and metrics
+            for grp in (1, 3):
+                trainer.cfg.eval_batch_group = grp
+                again = trainer.validate(CDAEBatchLoader(data, mode, batch_size=B, neg_times=3, seed=7, lists=True))
+                np.testing.assert_allclose(again[0], got[0], rtol=2e-6)
+                assert tuple(again[1:]) == tuple(got[1:])
+            trainer.cfg.eval_batch_group = 8
             np.testing.assert_allclose(got[1:], want[1:], atol=1e-3, rtol=0)     # the project's bar for the metrics:
         else:                                                                    # a float near-tie at rank 10 / 11
             got, want = trainer.evaluate(as_lists), trainer.evaluate(dense)      # may move one membership

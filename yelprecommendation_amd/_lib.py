@@ -62,6 +62,9 @@ SIGNATURES = {
     "yr_cdae_compact_pair": [_p, _p, _i64, _i64, C.c_uint64, _d, _p, _p, _p, _p, _p, _p, _p],
     "yr_cdae_train_lists": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _int, C.c_uint64, C.c_uint64, _d, _p, _p, _p, _p, _p,
                             _p, _p, _p],
+    "yr_cdae_train_lists_batched": [_p, _p, _p, _p, _p, _i64, _i64, _i64, _int, _p, _p, _i64, _d, _p, _p, _p, _p, _p,
+                                    _p, _p, _p],
+    "yr_cdae_loss_finalize_batched": [_p, _int, _p, _i64, _i64, _p, _p, _p, _p],
     "yr_cdae_loss_finalize": [_p, _i64, _p, _p, _p, _p],
     "yr_cdae_sampled_decode_splits": [_i64],
     "yr_cdae_sampled_decode": [_p, _p, _p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p, _p, _p, _p, _p],

@@ -49,6 +49,7 @@ __device__ __forceinline__ float cl_u01(uint32_t x) { return (float)(x >> 8) * (
 __global__ __launch_bounds__(kListThreads) void cdae_train_lists_kernel(
     const int64_t* __restrict__ ptr, const int64_t* __restrict__ idx, const int64_t* __restrict__ ptr2,
     const int64_t* __restrict__ idx2, const int64_t* __restrict__ users, int64_t num_users, int64_t I, int neg_times, uint64_t neg_seed, uint64_t drop_seed, float p, float scale,
+    const uint64_t* __restrict__ neg_seeds, const uint64_t* __restrict__ drop_seeds, int64_t batch_rows,
     int64_t cpp, int words, int32_t* __restrict__ cols, float* __restrict__ vals, int32_t* __restrict__ count,
     int32_t* __restrict__ lcols, float* __restrict__ lvals, int32_t* __restrict__ lcount,
     int32_t* __restrict__ err_flag) {
@@ -59,6 +60,13 @@ __global__ __launch_bounds__(kListThreads) void cdae_train_lists_kernel(
   uint32_t* s_pos = ptr2 ? s_bits + 2 * words : s_bits;   // loss positives: input items + those of (ptr2, idx2)
   const int nmaps = ptr2 ? 3 : 2;
   const int64_t r = blockIdx.x;
+  // Several batches in one launch (yr_cdae_train_lists_batched): row r is row rl = r % batch_rows of batch
+  // r / batch_rows and takes that batch's seeds — the lists are then exactly those of one launch per batch.
+  const int64_t rl = neg_seeds ? r % batch_rows : r;
+  if (neg_seeds) {
+    neg_seed = neg_seeds[r / batch_rows];
+    drop_seed = drop_seeds[r / batch_rows];
+  }
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   for (int w = tid; w < nmaps * words; w += kListThreads) s_bits[w] = 0u;
   if (tid == 0) { s_got = 0; s_bad = 0; }
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(kListThreads) void cdae_train_lists_kernel(
     const int k = min(target - got, kListThreads);
     if (tid < k) {
       const uint64_t d = next + tid;
-      const uint4 w = cl_philox(make_uint4((uint32_t)d, (uint32_t)(d >> 32), (uint32_t)r, (uint32_t)(r >> 32)), nkey, 7);
+      const uint4 w = cl_philox(make_uint4((uint32_t)d, (uint32_t)(d >> 32), (uint32_t)rl, (uint32_t)(rl >> 32)), nkey, 7);
       const uint64_t m = (uint64_t)w.x * span;
       if ((uint32_t)m >= lemire_min) {
         const uint32_t it = (uint32_t)(m >> 32);
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(kListThreads) void cdae_train_lists_kernel(
       if (is_in) {
         v = 1.0f;
         if (p > 0.0f) {
-          const int64_t e = r * I + c;              // flat position of the dense batch: its Philox group and word
+          const int64_t e = rl * I + c;             // flat position of the dense batch: its Philox group and word
           const uint4 w = cl_philox(make_uint4((uint32_t)(e >> 2), (uint32_t)((e >> 2) >> 32), 0u, 0u), dkey, 10);
           const uint32_t word = (e & 3) == 0 ? w.x : (e & 3) == 1 ? w.y : (e & 3) == 2 ? w.z : w.w;
           v = cl_u01(word) >= p ? scale : 0.0f;
@@ -180,11 +188,12 @@ __global__ __launch_bounds__(kListThreads) void cdae_train_lists_kernel(
 
 using namespace yr;
 
-extern "C" int yr_cdae_train_lists(const int64_t* ptr, const int64_t* idx, const int64_t* ptr2, const int64_t* idx2,
-                                   const int64_t* users, int64_t B,
-                                   int64_t num_users, int64_t I, int neg_times, uint64_t neg_seed, uint64_t drop_seed,
-                                   double p, int32_t* cols, float* vals, int32_t* count, int32_t* loss_cols,
-                                   float* loss_targets, int32_t* loss_count, int32_t* err_flag, void* stream) {
+static int train_lists_impl(const int64_t* ptr, const int64_t* idx, const int64_t* ptr2, const int64_t* idx2,
+                            const int64_t* users, int64_t B, int64_t num_users, int64_t I, int neg_times,
+                            uint64_t neg_seed, uint64_t drop_seed, const uint64_t* neg_seeds, const uint64_t* drop_seeds,
+                            int64_t batch_rows, double p, int32_t* cols, float* vals, int32_t* count,
+                            int32_t* loss_cols, float* loss_targets, int32_t* loss_count, int32_t* err_flag,
+                            void* stream) {
   if (B < 0 || num_users <= 0 || I <= 0 || neg_times < 0 || p < 0.0 || p >= 1.0 || B > 0x7fffffff) return YR_ERR_BADARG;
   if (I > 0x7fffffff) return YR_ERR_UNSUPPORTED;
   if (B == 0) return 0;
@@ -195,7 +204,28 @@ extern "C" int yr_cdae_train_lists(const int64_t* ptr, const int64_t* idx, const
   if (lds > 60 * 1024) return YR_ERR_UNSUPPORTED;        // catalogues beyond ~245 k items: the dense route
   const int64_t cpp = ((I + kListParts - 1) / kListParts + 3) / 4 * 4;   // == yr_cdae_sparse_part_columns(I)
   hipLaunchKernelGGL(cdae_train_lists_kernel, dim3((unsigned)B), dim3(kListThreads), lds, (hipStream_t)stream, ptr, idx, ptr2,
-                     idx2, users, num_users, I, neg_times, neg_seed, drop_seed, (float)p, (float)(1.0 / (1.0 - p)), cpp, words,
+                     idx2, users, num_users, I, neg_times, neg_seed, drop_seed, (float)p, (float)(1.0 / (1.0 - p)), neg_seeds, drop_seeds,
+                     batch_rows, cpp, words,
                      cols, vals, count, loss_cols, loss_targets, loss_count, err_flag);
   return launch_status();
+}
+
+extern "C" int yr_cdae_train_lists(const int64_t* ptr, const int64_t* idx, const int64_t* ptr2, const int64_t* idx2,
+                                   const int64_t* users, int64_t B,
+                                   int64_t num_users, int64_t I, int neg_times, uint64_t neg_seed, uint64_t drop_seed,
+                                   double p, int32_t* cols, float* vals, int32_t* count, int32_t* loss_cols,
+                                   float* loss_targets, int32_t* loss_count, int32_t* err_flag, void* stream) {
+  return train_lists_impl(ptr, idx, ptr2, idx2, users, B, num_users, I, neg_times, neg_seed, drop_seed, nullptr, nullptr,
+                          0, p, cols, vals, count, loss_cols, loss_targets, loss_count, err_flag, stream);
+}
+
+extern "C" int yr_cdae_train_lists_batched(const int64_t* ptr, const int64_t* idx, const int64_t* ptr2,
+                                           const int64_t* idx2, const int64_t* users, int64_t B, int64_t num_users,
+                                           int64_t I, int neg_times, const uint64_t* neg_seeds,
+                                           const uint64_t* drop_seeds, int64_t batch_rows, double p, int32_t* cols,
+                                           float* vals, int32_t* count, int32_t* loss_cols, float* loss_targets,
+                                           int32_t* loss_count, int32_t* err_flag, void* stream) {
+  if (!neg_seeds || !drop_seeds || batch_rows <= 0) return YR_ERR_BADARG;
+  return train_lists_impl(ptr, idx, ptr2, idx2, users, B, num_users, I, neg_times, 0, 0, neg_seeds, drop_seeds,
+                          batch_rows, p, cols, vals, count, loss_cols, loss_targets, loss_count, err_flag, stream);
 }

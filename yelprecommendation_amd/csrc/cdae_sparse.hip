@@ -473,9 +473,57 @@ __global__ __launch_bounds__(kBlock) void cdae_loss_finalize_kernel(const float*
   }
 }
 
+// The validation loss of SEVERAL batches scored by one yr_cdae_sampled_decode launch: workgroup q sums the loss
+// partials and the position counts (loss_count, kParts per row) of the rows of batch q -> mean_q; the last
+// workgroup to arrive adds the means in batch order (fixed order) to *loss_accum.  `arrive` is zero on entry and is
+// left zero.
+__global__ __launch_bounds__(kBlock) void cdae_loss_finalize_batched_kernel(
+    const float* __restrict__ partial_loss, int splits, const int32_t* __restrict__ loss_count, int64_t rows,
+    int64_t batch_rows, float* __restrict__ means, int32_t* __restrict__ arrive, double* __restrict__ loss_accum) {
+  __shared__ float s_red[kWavesPerBlock];
+  __shared__ int s_cnt[kWavesPerBlock];
+  __shared__ int s_last;
+  const int64_t r0 = (int64_t)blockIdx.x * batch_rows, r1 = min(rows, r0 + batch_rows);
+  float s = 0.0f;
+  for (int64_t k = r0 * splits + threadIdx.x; k < r1 * splits; k += kBlock) s += partial_loss[k];
+  int c = 0;
+  for (int64_t k = r0 * kParts + threadIdx.x; k < r1 * kParts; k += kBlock) c += loss_count[k];
+#pragma unroll
+  for (int d = kWave / 2; d >= 1; d >>= 1) c += __shfl_xor(c, d, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) s_cnt[threadIdx.x / kWave] = c;
+  const float tot = block_sum(s, s_red);
+  if (threadIdx.x == 0) {
+    int cnt = 0;
+    for (int w = 0; w < kWavesPerBlock; ++w) cnt += s_cnt[w];
+    means[blockIdx.x] = cnt > 0 ? tot / (float)cnt : 0.0f;
+    __threadfence();
+    s_last = atomicAdd(arrive, 1) == (int)gridDim.x - 1;
+    if (s_last) {
+      __threadfence();
+      double acc = 0.0;
+      for (unsigned q = 0; q < gridDim.x; ++q) acc += (double)__builtin_nontemporal_load(means + q);
+      if (loss_accum) loss_accum[0] += acc;
+      *arrive = 0;
+    }
+  }
+}
+
 }  // namespace yr
 
 using namespace yr;
+
+extern "C" int yr_cdae_loss_finalize_batched(const float* partial_loss, int splits, const int32_t* loss_count,
+                                             int64_t rows, int64_t batch_rows, float* means, int32_t* arrive,
+                                             double* loss_accum, void* stream) {
+  if (rows < 0 || batch_rows <= 0 || splits <= 0) return YR_ERR_BADARG;
+  if (rows == 0) return 0;
+  if (!partial_loss || !loss_count || !means || !arrive) return YR_ERR_BADARG;
+  const int64_t batches = (rows + batch_rows - 1) / batch_rows;
+  if (batches > 65535) return YR_ERR_BADARG;
+  hipLaunchKernelGGL(cdae_loss_finalize_batched_kernel, dim3((unsigned)batches), dim3(kBlock), 0, (hipStream_t)stream,
+                     partial_loss, splits, loss_count, rows, batch_rows, means, arrive, loss_accum);
+  return launch_status();
+}
 
 extern "C" int64_t yr_cdae_sparse_part_columns(int64_t I) {
   // columns per part: I / 32 rounded up to a multiple of 4

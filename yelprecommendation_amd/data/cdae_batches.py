@@ -151,6 +151,36 @@ class CDAEBatchLoader:
         seed = int(torch.randint(0, 1 << 62, (1,), generator=self._seeds).item())
         return engine.negative_mask(positives.contiguous(), self.neg_times, seed, err_flag=self._flag)
 
+    def super_batches(self, group=8):
+        """lists=True, mode 'valid' / 'test': the same batches, ``group`` at a time — ``{"user_id" (all rows of the
+        group), "lists" (one engine.TrainLists over them, made by ONE launch with the seeds of the single batches),
+        "batch_rows", "item_lists"}``.  The host generators are consumed exactly as by ``__iter__`` (one permutation,
+        two seeds per batch), so the lists — and every number derived from them — are those of the per-batch
+        iteration; CDAETrainer.validate / evaluate then need a handful of launches per group instead of ~10 per
+        batch."""
+        if not self.lists or self.mode == "train":
+            raise ValueError("super_batches: list batches of the 'valid' / 'test' loaders")
+        d = self.data
+        order = (torch.randperm(d.num_users, generator=self._gen, device=d.device) if self.shuffle
+                 else torch.arange(d.num_users, device=d.device))
+        bs = self.batch_size
+        lists = {"users": None, "actual": d.csr("test" if self.mode == "test" else "valid"),
+                 "seen": d.csr("train_valid" if self.mode == "test" else "train")}
+        for s in range(0, d.num_users, bs * group):
+            users = order[s:s + bs * group].contiguous()
+            nb = -(-users.numel() // bs)
+            seeds = torch.randint(0, 1 << 62, (nb, 2), generator=self._seeds)      # the draws of nb single batches
+            seeds = seeds.to(d.device)
+            ptr, idx = d.csr("train_valid" if self.mode == "test" else "train")
+            made = engine.TrainLists(ptr, idx, users, d.num_users, d.num_items, 0 if self.mode == "test" else self.neg_times,
+                                     seeds[:, 0].contiguous(), seeds[:, 1].contiguous(), 0.0, err_flag=self._flag,
+                                     extra=d.csr("valid") if self.mode == "valid" else None, pool=self._list_pool,
+                                     batch_rows=bs)
+            yield {"user_id": users, "lists": made, "batch_rows": bs, "item_lists": dict(lists, users=users)}
+        if self._flag is not None and int(self._flag.item()):
+            self._flag.zero_()
+            raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+
     def __iter__(self):
         d = self.data
         order = (torch.randperm(d.num_users, generator=self._gen, device=d.device) if self.shuffle

@@ -496,9 +496,12 @@ class TrainLists:
     _pool = {}
 
     def __init__(self, ptr, idx, users, num_users, num_items, neg_times, neg_seed, drop_seed, p, err_flag=None,
-                 extra=None, pool=None):
+                 extra=None, pool=None, batch_rows=None):
         """``extra``: (ptr, idx) of a second per-user CSR whose items are positives of the loss list too (the
-        held-out items in validation) without entering the encoder list."""
+        held-out items in validation) without entering the encoder list.
+        ``batch_rows``: ``users`` holds SEVERAL batches of that many rows (the last may be short) and ``neg_seed`` /
+        ``drop_seed`` are int64 device tensors with one seed per batch — one launch makes exactly the lists one
+        TrainLists per batch would (yr_cdae_train_lists_batched)."""
         lib = _lib.load()
         B, I = users.numel(), int(num_items)
         dev = users.device
@@ -517,12 +520,24 @@ class TrainLists:
         buf = slot[0]
         i64 = torch.int64
         some = lambda t: t if t.numel() else torch.zeros(1, dtype=i64, device=dev)   # an empty index: never read, needs an address
-        check(lib.yr_cdae_train_lists(_dev(ptr, i64, "ptr"), _dev(some(idx), i64, "idx"),
-                                      None if extra is None else _dev(extra[0], i64, "ptr2"),
-                                      None if extra is None else _dev(some(extra[1]), i64, "idx2"), _dev(users, i64, "users"), B,
-                                      int(num_users), I, int(neg_times), int(neg_seed) & (2**64 - 1),
-                                      int(drop_seed) & (2**64 - 1), float(p), *(t.data_ptr() for t in buf),
-                                      _opt(err_flag, torch.int32, "err_flag"), _stream()), "yr_cdae_train_lists")
+        if batch_rows is not None:
+            nb = -(-B // int(batch_rows)) if B else 0
+            if not (torch.is_tensor(neg_seed) and torch.is_tensor(drop_seed) and neg_seed.numel() >= nb
+                    and drop_seed.numel() >= nb):
+                raise EngineError("batched TrainLists: one neg / drop seed per batch (int64 device tensors)")
+            check(lib.yr_cdae_train_lists_batched(
+                _dev(ptr, i64, "ptr"), _dev(some(idx), i64, "idx"), None if extra is None else _dev(extra[0], i64, "ptr2"),
+                None if extra is None else _dev(some(extra[1]), i64, "idx2"), _dev(users, i64, "users"), B, int(num_users),
+                I, int(neg_times), _dev(neg_seed, i64, "neg_seeds"), _dev(drop_seed, i64, "drop_seeds"), int(batch_rows),
+                float(p), *(t.data_ptr() for t in buf), _opt(err_flag, torch.int32, "err_flag"), _stream()),
+                "yr_cdae_train_lists_batched")
+        else:
+            check(lib.yr_cdae_train_lists(_dev(ptr, i64, "ptr"), _dev(some(idx), i64, "idx"),
+                                          None if extra is None else _dev(extra[0], i64, "ptr2"),
+                                          None if extra is None else _dev(some(extra[1]), i64, "idx2"), _dev(users, i64, "users"), B,
+                                          int(num_users), I, int(neg_times), int(neg_seed) & (2**64 - 1),
+                                          int(drop_seed) & (2**64 - 1), float(p), *(t.data_ptr() for t in buf),
+                                          _opt(err_flag, torch.int32, "err_flag"), _stream()), "yr_cdae_train_lists")
         self.rows = SparseRows.from_buffers(buf[0], buf[1], buf[2], B, I)
         self.loss = (buf[3], buf[4], buf[5])
         self.B, self.I = B, I
@@ -561,6 +576,17 @@ def cdae_sampled_decode(loss_lists, z, Wo, bo, act, dz, dWo, dbo, partial_loss, 
                                      _opt(bo, f32, "bo"), B, I, H, int(act), _opt(dz, f32, "dz"), _opt(dWo, f32, "dWo"),
                                      _opt(dbo, f32, "dbo"), _dev(partial_loss, f32, "partial_loss"), _dev(count, torch.int32, "count"),
                                      _stream()), "yr_cdae_sampled_decode")
+
+
+def cdae_loss_finalize_batched(partial_loss, splits, loss_count, rows, batch_rows, means, arrive, loss_accum):
+    """loss_accum += sum over the batches of ``batch_rows`` rows of (the batch's loss partials / its positions):
+    the validation loss of several batches scored by one cdae_sampled_decode launch (yr_cdae_loss_finalize_batched)."""
+    lib = _lib.load()
+    check(lib.yr_cdae_loss_finalize_batched(_dev(partial_loss, torch.float32, "partial_loss"), int(splits),
+                                            _dev(loss_count, torch.int32, "loss_count"), int(rows), int(batch_rows),
+                                            _dev(means, torch.float32, "means"), _dev(arrive, torch.int32, "arrive"),
+                                            _opt(loss_accum, torch.float64, "loss_accum"), _stream()),
+          "yr_cdae_loss_finalize_batched")
 
 
 def cdae_loss_finalize(partial_loss, n_partials, count, stats, loss_accum=None):

@@ -120,18 +120,42 @@ class CDAETrainer(BaseTrainer):
         if with_loss and not self.cfg.negative_sampling:
             raise NotImplementedError("list batches carry the NS-BCE positions; plain BCE needs dense batches")
         Wh, bh, V, Wo, bo = (q.data for q in model._params())
+        # the encoder gathers one column of W_h per input item: from a transposed copy ([I, H], made once per pass:
+        # one 19.5 MB copy) that is one contiguous 4 H-byte row instead of H scattered cache lines — the encoder was
+        # the largest kernel of a validation pass after the scoring launch (1.7 ms of 5.4)
+        WhT = Wh.t().contiguous() if model.hidden_size % 4 == 0 else None
         Z = torch.zeros(model.num_users, model.hidden_size, dtype=torch.float32, device=dev)   # rows by user id
         covered, item_lists = 0, None
         stats = torch.zeros(2, dtype=torch.float32, device=dev)
         count = torch.zeros(engine.COUNT_WORDS, dtype=torch.int32, device=dev)
         partials = None
-        for data in dataloader:
+        # several batches per launch when the loader can make them (CDAEBatchLoader.super_batches: the same lists, the
+        # same loss per batch; ~10 engine calls per GROUP of batches instead of per batch — the per-batch loop was
+        # bound by its host calls: 72 us per 256-row batch for 42 us of kernels)
+        group = int(self.cfg.get("eval_batch_group", 16))
+        grouped = group > 1 and hasattr(dataloader, "super_batches")
+        means = arrive = None
+        for data in (dataloader.super_batches(group) if grouped else dataloader):
             users, lists = data['user_id'].to(dev).contiguous(), data['lists'].alive()
-            z = engine.cdae_sparse_encode(lists.rows, Wh, bh, V, users, model._hidden_act, err_flag=model._flag())
+            z = (engine.cdae_sparse_encode(lists.rows, WhT, bh, V, users, model._hidden_act, err_flag=model._flag(),
+                                           transposed=True) if WhT is not None else
+                 engine.cdae_sparse_encode(lists.rows, Wh, bh, V, users, model._hidden_act, err_flag=model._flag()))
             Z.index_copy_(0, users, z)
             covered += users.numel()
             item_lists = data['item_lists']
-            if with_loss:
+            if with_loss and grouped:
+                splits = engine.cdae_sampled_decode_splits(users.numel())
+                n = users.numel() * splits
+                if partials is None or partials.numel() < n:
+                    partials = torch.empty(n, dtype=torch.float32, device=dev)
+                if means is None:
+                    means = torch.zeros(max(group, 1), dtype=torch.float32, device=dev)
+                    arrive = torch.zeros(1, dtype=torch.int32, device=dev)
+                count.zero_()
+                engine.cdae_sampled_decode(lists.loss, z, Wo, bo, model._output_act, None, None, None, partials, count)
+                engine.cdae_loss_finalize_batched(partials, splits, lists.loss[2], users.numel(), data['batch_rows'],
+                                                  means, arrive, self._loss_accum)
+            elif with_loss:
                 n = users.numel() * engine.cdae_sampled_decode_splits(users.numel())
                 if partials is None or partials.numel() < n:
                     partials = torch.empty(n, dtype=torch.float32, device=dev)
