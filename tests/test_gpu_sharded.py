@@ -173,7 +173,7 @@ def test_exchange_over_rccl_single_rank(tmp_path, device):
 
 # ------------------------------------------------------------------------------------------------
 # The user-sharded MFTrainer (2 ranks on cuda:0 over gloo) against the single-process trainer
-def _trainer_problem(tmp):
+def _trainer_problem(tmp, optimizer="adam"):
     import pandas as pd
     from yelprecommendation_amd.data.synthetic import make_frame
     from yelprecommendation_amd.data.datasets.mf_data_pipeline import MFDataPipeline
@@ -181,6 +181,8 @@ def _trainer_problem(tmp):
     from yelprecommendation_amd.utils import make_config
     cfg = make_config("MF", embed_size=32, lr=5e-3, batch_size=512, epochs=3, device="cuda", model_dir=tmp,
                       seed=42, top_n=10, patience=5, best_metric="recall")
+    if optimizer == "sgd":                     # plain SGD moves slowly: a large step and some weight decay
+        cfg.update(optimizer="sgd", lr=2.0, weight_decay=1e-3)
     pipe = MFDataPipeline(cfg)
     df = make_frame(150, 120, 14.0)
     pipe._load_df = lambda: df
@@ -190,11 +192,11 @@ def _trainer_problem(tmp):
         valid_eval, test_eval
 
 
-def _run_trainer(tmp):
+def _run_trainer(tmp, optimizer="adam"):
     from torch.utils.data import DataLoader
     from yelprecommendation_amd.trainers.mf_trainer import MFTrainer
     from yelprecommendation_amd.utils import set_seed
-    cfg, pipe, train_ds, valid_ds, valid_eval, test_eval = _trainer_problem(tmp)
+    cfg, pipe, train_ds, valid_ds, valid_eval, test_eval = _trainer_problem(tmp, optimizer)
     set_seed(cfg.seed)
     trainer = MFTrainer(cfg, pipe.num_items, pipe.num_users)
     trainer.run(DataLoader(train_ds, batch_size=cfg.batch_size, shuffle=True),
@@ -203,11 +205,11 @@ def _run_trainer(tmp):
     return trainer, trainer.evaluate(test_eval, 'test')
 
 
-def _trainer_worker(rank, world, port, out_dir):
+def _trainer_worker(rank, world, port, out_dir, optimizer="adam"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    trainer, metrics = _run_trainer(os.path.join(out_dir, "sharded"))
+    trainer, metrics = _run_trainer(os.path.join(out_dir, "sharded"), optimizer)
     assert trainer.world_size == world and trainer.shard.rank == rank
     np.savez(os.path.join(out_dir, f"trainer_rank{rank}.npz"), metrics=np.asarray(metrics),
              U=trainer.model.user_embedding.weight.detach().cpu().numpy(),
@@ -216,14 +218,17 @@ def _trainer_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(900)
-def test_sharded_trainer_matches_single_process(tmp_path, device):
+@pytest.mark.parametrize("optimizer", ["adam", "sgd"])
+def test_sharded_trainer_matches_single_process(tmp_path, device, optimizer):
     """MFTrainer.run + load_best_model + evaluate under a 2-rank group == the same calls in one
     process: tables to float rounding (summation order of the item gradient), metrics identical
-    on every rank and within 1e-3 of the single-process ones."""
+    on every rank and within 1e-3 of the single-process ones — with Adam (the fused step + item-gradient exchange)
+    and with SGD + weight decay (reference trainers/base_trainer.py:39-40: scatter kernel, all-reduce, dense update
+    of the item table and of the rank's own user rows)."""
     world = 2
     os.makedirs(os.path.join(str(tmp_path), "sharded"), exist_ok=True)
-    mp.spawn(_trainer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    single, want = _run_trainer(os.path.join(str(tmp_path), "single"))
+    mp.spawn(_trainer_worker, args=(world, _free_port(), str(tmp_path), optimizer), nprocs=world, join=True)
+    single, want = _run_trainer(os.path.join(str(tmp_path), "single"), optimizer)
     outs = [np.load(os.path.join(str(tmp_path), f"trainer_rank{r}.npz")) for r in range(world)]
     np.testing.assert_array_equal(outs[0]["metrics"], outs[1]["metrics"])
     np.testing.assert_allclose(outs[0]["metrics"], np.asarray(want), atol=1e-3)

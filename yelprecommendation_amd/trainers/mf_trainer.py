@@ -151,7 +151,7 @@ class MFTrainer(BaseTrainer):
         self.model.train()
         step = self._fused_step()
         if step is None and self.world_size > 1:
-            raise NotImplementedError("user-sharded training needs optimizer adam or adamw")
+            return self._train_sharded_sgd(train_dataloader)
         if step is None:                                   # SGD: fused fwd/bwd kernel + dense update
             self._loss_accum.zero_()
             for data in train_dataloader:
@@ -196,6 +196,38 @@ class MFTrainer(BaseTrainer):
             _dist().all_reduce(step.flag, op=_dist().ReduceOp.MAX)
         step.check()
         return total
+
+    def _train_sharded_sgd(self, train_dataloader) -> float:
+        """SGD (trainers/base_trainer.py:39-40) under user sharding: every rank scatters the gradients of the
+        triplets whose users it owns with 1 / B_global (the mean of loss.py:27 over the whole batch), the dense
+        item gradient is all-reduced (RCCL), and the dense update — p -= lr (g + wd p) — is applied to the item table
+        (identical on every rank) and to the rank's OWN user rows; the other user rows arrive with the per-epoch
+        exchange.  Equal to the single-process SGD epoch up to summation order."""
+        dist = _dist()
+        from .. import optim
+        if not isinstance(self.optimizer, optim.SGD):
+            raise NotImplementedError(f"user-sharded training: optimizer {type(self.optimizer).__name__}")
+        U, I = self.model.user_embedding.weight, self.model.item_embedding.weight
+        group = self.optimizer.param_groups[0]
+        lo, hi = self.shard.lo, self.shard.hi
+        self._loss_accum.zero_()
+        for data in train_dataloader:
+            user_id, pos_item, neg_item = self._batch(data)
+            B = user_id.numel()
+            mine = self.shard.mine(user_id)
+            self.model.bpr_loss_backward(user_id[mine].contiguous(), pos_item[mine].contiguous(),
+                                         neg_item[mine].contiguous(), loss_accum=self._loss_accum,
+                                         inv_batch=1.0 / B if B else 0.0)
+            dist.all_reduce(I.grad, op=dist.ReduceOp.SUM)
+            engine.sgd_dense(I.data, I.grad, group["lr"], group["weight_decay"], zero_grad=True)
+            if hi > lo:
+                engine.sgd_dense(U.data[lo:hi], U.grad[lo:hi], group["lr"], group["weight_decay"], zero_grad=True)
+        self._exchange_user_rows()
+        dist.all_reduce(self._loss_accum, op=dist.ReduceOp.SUM)      # per-rank partial means (already / B_global)
+        flag = self.model._flag()
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)                  # a bad index raises on every rank together
+        self.model.check_indices()
+        return float(self._loss_accum.item())
 
     def save_checkpoint(self, path, **extra):
         """As BaseTrainer.save_checkpoint; when the run is user-sharded, rank r holds the current Adam
