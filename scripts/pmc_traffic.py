@@ -30,7 +30,12 @@ def per_kernel(d, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
+# the launches of the STEP only (the input generation of bench.py — triplet_sample_kernel — runs once, before it)
+import re
+STEP_KERNELS = re.compile(r"tile_partition_kernel|owner_pass_kernel|bpr_fwd_bwd_kernel|adam_dual_kernel|adam_dense_kernel")
 fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+fetch = {k: v for k, v in fetch.items() if STEP_KERNELS.search(k)}
+write = {k: v for k, v in write.items() if STEP_KERNELS.search(k)}
 rows, total = [], 0.0
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, 0.0) * 1024, write.get(k, 0.0) * 1024

@@ -493,8 +493,10 @@ def test_fused_step_equals_autograd_route(device, tmp_path, batch, fraction, opt
     np.testing.assert_allclose(la[0], lb[0], rtol=3e-7)     # the same scores; the batch mean summed in another order
     np.testing.assert_allclose(la, lb, rtol=2e-5)
     for k in pa:
-        scale = float(pb[k].abs().max())
-        torch.testing.assert_close(pa[k], pb[k], rtol=1e-3, atol=1e-5 * scale, msg=lambda m: f"{k}: {m}")
+        # parameters: where a gradient cancels to the order of Adam's eps, m / sqrt(v) turns the summation-order noise
+        # of the float atomics into a few per cent of lr per step — allowed on the parameters (2 % of
+        # lr x steps), never on the moments, which are linear in the gradients
+        torch.testing.assert_close(pa[k], pb[k], rtol=1e-3, atol=0.02 * 2e-3 * 6, msg=lambda m: f"{k}: {m}")
         assert sa[k][0] == sb[k][0] == 6
         torch.testing.assert_close(sa[k][1], sb[k][1], rtol=1e-3, atol=1e-6 * float(sb[k][1].abs().max()), msg=lambda m: f"m {k}: {m}")
         torch.testing.assert_close(sa[k][2], sb[k][2], rtol=1e-3, atol=1e-6 * float(sb[k][2].abs().max()), msg=lambda m: f"v {k}: {m}")
