@@ -708,7 +708,14 @@ if __name__ == "__main__":
         golden_mf_full(os.path.join(HERE, "mf_full.npz"))
     if "ngcf" in which:
         golden_ngcf(os.path.join(HERE, "ngcf_tiny.npz"))
+        # BASELINE configs[3]'s hyper-parameters (D = 64, K = 3 layers) on a graph the reference can still propagate
+        # on CPU (it builds eye(N, N) per layer per batch)
+        golden_ngcf(os.path.join(HERE, "ngcf_mid.npz"), num_users=600, num_items=500, mean_items=14.0, embed=64,
+                    orders=3, lr=2e-3, batch=256, epochs=2, seed=42)
     if "cdae" in which:
         golden_cdae(os.path.join(HERE, "cdae_small.npz"))
+        # BASELINE configs[4]'s hidden size (H = 128) and the reference's default batch (32) on a ~500-item catalogue
+        golden_cdae(os.path.join(HERE, "cdae_mid.npz"), num_users=256, num_items=700, mean_items=16.0, hidden=128,
+                    lr=2e-3, batch=32, epochs=2, seed=42)
     if "metric" in which:
         golden_metric(os.path.join(HERE, "metric_cases.npz"))

@@ -12,9 +12,11 @@ from oracle import cdae as ocdae
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def g(golden_dir):
-    return np.load(os.path.join(golden_dir, "cdae_small.npz"))
+# two captures of the reference: the small one (H = 16) and one with BASELINE configs[4]'s hidden size (H = 128) at the
+# reference's default batch 32 (tests/golden/make_golden.py cdae)
+@pytest.fixture(scope="module", params=["cdae_small.npz", "cdae_mid.npz"])
+def g(golden_dir, request):
+    return np.load(os.path.join(golden_dir, request.param))
 
 
 @pytest.mark.parametrize("tA", [False, True])

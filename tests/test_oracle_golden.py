@@ -135,10 +135,11 @@ def test_best_epoch_is_argmin_valid_loss(g):
 
 
 # --------------------------------------------------------------------------- NGCF oracle
-def test_ngcf_oracle_matches_reference(golden_dir):
+@pytest.mark.parametrize("capture", ["ngcf_tiny.npz", "ngcf_mid.npz"])
+def test_ngcf_oracle_matches_reference(golden_dir, capture):
     import scipy.sparse as sp
     from oracle import ngcf as on
-    g = np.load(os.path.join(golden_dir, "ngcf_tiny.npz"))
+    g = np.load(os.path.join(golden_dir, capture))
     U, I, K = int(g["num_users"]), int(g["num_items"]), int(g["num_orders"])
     L = on.laplacian_csr(g["tsv_user"], g["tsv_item"], g["tsv_rating"], U, I)
     Lref = sp.csr_matrix((g["lap_val"], (g["lap_row"], g["lap_col"])), shape=(U + I, U + I))
@@ -167,15 +168,24 @@ def test_ngcf_oracle_matches_reference(golden_dir):
             s = slice(pos_, pos_ + int(b)); pos_ += int(b)
             tot += float(st.train_step(*(g[k][s].astype(np.int64) for k in ("train_u", "train_p", "train_n"))))
         bp += ns
-        np.testing.assert_allclose(tot, g["train_epoch_loss"][e], rtol=1e-6)
-    np.testing.assert_allclose(st.E, g["final__embedding__weight"], rtol=0, atol=2e-6)
-    np.testing.assert_allclose(st.W2[1], g["final__W2__1__weight"], rtol=0, atol=2e-6)
+        # a NumPy restatement against torch's kernels: float32 summation order.  The tiny capture (D = 16, K = 2) agrees
+        # to 1e-6; with D = 64, K = 3 and N(0, 1) embeddings the scores are in the hundreds and 38 Adam steps at
+        # lr 2e-3 pass a few 1e-6 on — still two orders inside the project's bars (loss 1e-4, weights 1e-3)
+        mid = int(g["embed_size"]) >= 64
+        np.testing.assert_allclose(tot, g["train_epoch_loss"][e], rtol=2e-5 if mid else 1e-6)
+    # Adam moves a parameter by at most lr per step whatever the size of its gradient, so where a gradient nearly
+    # cancels (the D x D weights sum over all nodes) summation-order noise becomes a visible fraction of lr: the bar
+    # for the larger capture is 1 % of the maximum travel lr x steps (+ rtol 1e-3), the tiny one keeps 2e-6
+    travel = float(g["lr"]) * int(np.sum(g["train_steps"]))
+    np.testing.assert_allclose(st.E, g["final__embedding__weight"], rtol=1e-3 if mid else 0, atol=0.01 * travel if mid else 2e-6)
+    np.testing.assert_allclose(st.W2[1], g["final__W2__1__weight"], rtol=1e-3 if mid else 0, atol=0.01 * travel if mid else 2e-6)
 
 
 # --------------------------------------------------------------------------- CDAE oracle
-def test_cdae_oracle_matches_reference(golden_dir):
+@pytest.mark.parametrize("capture", ["cdae_small.npz", "cdae_mid.npz"])
+def test_cdae_oracle_matches_reference(golden_dir, capture):
     from oracle import cdae as oc
-    g = np.load(os.path.join(golden_dir, "cdae_small.npz"))
+    g = np.load(os.path.join(golden_dir, capture))
     names = [n.replace(".", "__") for n in g["param_names"]]
     assert names == ["hidden_layer__weight", "hidden_layer__bias", "user_nodes__weight",
                      "output_layer__weight", "output_layer__bias"]
@@ -214,4 +224,4 @@ def test_cdae_oracle_matches_reference(golden_dir):
              ometric.map_at_k(acts, pred, 10), ometric.ndcg_at_k(acts, pred, 10))
         np.testing.assert_allclose(m, g["valid_epoch"][e][1:], rtol=1e-9, atol=1e-12)
     for n, p in zip(names, st.params):
-        np.testing.assert_allclose(p, g["final__" + n], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(p, g["final__" + n], rtol=0, atol=2e-6 if int(g["hidden_size"]) < 128 else 1e-5)

@@ -71,7 +71,16 @@ constexpr int kHeavyRow = YR_HEAVY_ROW;          // records per row and chunk fr
 #define YR_SPLIT_MIN 2048
 #endif
 constexpr int kSplitMin = YR_SPLIT_MIN;          // records of a bucket from which it is split
-constexpr int kSplitTarget = 1024;               // records per part (one chunk of the item pass)
+#ifndef YR_SPLIT_AVG_MIN
+#define YR_SPLIT_AVG_MIN 2.5
+#endif
+#ifndef YR_SPLIT_AVG_TARGET
+#define YR_SPLIT_AVG_TARGET 1.25
+#endif
+#ifndef YR_SPLIT_TARGET
+#define YR_SPLIT_TARGET 1024
+#endif
+constexpr int kSplitTarget = YR_SPLIT_TARGET;    // records per part (one chunk of the item pass)
 constexpr int kMaxParts = 64;
 constexpr int kMaxTasks = 512;                   // helper workgroups at the front of the item pass's grid
 constexpr int kMaxSlots = 1024;                  // scratch slots of 1024 floats (one bucket's rows)
@@ -276,6 +285,7 @@ struct OwnerArgs {
   float* scratch;
   const int32_t* b_off;
   int helper_blocks, build_blocks, b_nb;
+  int b_split_min, b_split_target;   // records from which a bucket is split / per part (host: scaled with the batch)
 };
 
 // the pieces of the `split` block
@@ -312,8 +322,8 @@ __device__ __forceinline__ void build_splits(const OwnerArgs& a, int builder) {
   for (int m = 1; m < kBuildLanes; m <<= 1) total += __shfl_xor(total, m, kWave);
   if (k >= a.b_nb || j != 0) return;
   int parts = 1;
-  if (total >= kSplitMin) {
-    parts = (total + kSplitTarget - 1) / kSplitTarget;
+  if (total >= a.b_split_min) {
+    parts = (total + a.b_split_target - 1) / a.b_split_target;
     parts = min(parts, min(kMaxParts, a.T));
   }
   int slot = 0;
@@ -999,6 +1009,14 @@ static int pull_apply_impl(const float* U_old, float* U_new, float* I, float* mU
     // the last kSplitBuilders workgroups size the item buckets (oversize ones are shared out in the item pass)
     ua.build_blocks = (p.nbI * kBuildLanes + kBlock - 1) / kBlock;
     ua.b_off = (const int32_t*)(w + p.o_offI); ua.b_nb = p.nbI;
+    {
+      // oversize = well above the average bucket of THIS batch (2B occurrences over nbI buckets), and never below
+      // the floors: at one epoch per step the average bucket already holds 770 records
+      const double avg = 2.0 * (double)B / (double)p.nbI;
+      const int by_avg_min = (int)(YR_SPLIT_AVG_MIN * avg), by_avg_target = (int)(YR_SPLIT_AVG_TARGET * avg);
+      ua.b_split_min = by_avg_min > kSplitMin ? by_avg_min : kSplitMin;
+      ua.b_split_target = by_avg_target > kSplitTarget ? by_avg_target : kSplitTarget;
+    }
     ua.split = w + p.o_split;
     const int gu = (p.nbU < YR_LOSS_PARTIALS ? p.nbU : YR_LOSS_PARTIALS) + ua.build_blocks;   // one loss-partial slot per owner
     if (p.narrow_users && deterministic)
