@@ -469,7 +469,7 @@ def test_fused_step_equals_autograd_route(device, tmp_path, batch, fraction, opt
     graph = LaplacianCSR.from_interactions(u, i, r, nu, ni, device, heavy_threshold=128)
     batches = [tuple(torch.from_numpy(rs.randint(0, m, batch + 3 * k)).to(device) for m in (nu, ni, ni)) for k in range(6)]
     batches[3] = tuple(t[:0] for t in batches[3])                    # an empty batch: a step with zero gradients
-    out = {}
+    out, first = {}, {}
     for route in ("fused", "autograd"):
         torch.manual_seed(8)
         cfg = make_config("NGCF", embed_size=64, num_orders=3, device="cuda", model_dir=str(tmp_path),
@@ -480,15 +480,22 @@ def test_fused_step_equals_autograd_route(device, tmp_path, batch, fraction, opt
         opt = (AdamW(model.parameters(), lr=2e-3, weight_decay=0.05) if optimizer == "adamw"
                else Adam(model.parameters(), lr=2e-3))
         losses = []
+
+        def snapshot():
+            return ({k: p.detach().clone() for k, p in model.named_parameters()},
+                    {k: (opt.state[p]["step"], opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone())
+                     for k, p in model.named_parameters()})
         if route == "fused":
             step = NGCFStep(model, opt, graph, fraction)
-            for bu, bp, bn in batches:
+            for j, (bu, bp, bn) in enumerate(batches):
                 step.step(bu, bp, bn)
                 losses.append(float(step.last_loss().item()))
+                if j == 0:
+                    first[route] = snapshot()
             step.check()
             assert abs(step.epoch_loss() - sum(losses)) <= 1e-6 * abs(sum(losses))
         else:
-            for bu, bp, bn in batches:
+            for j, (bu, bp, bn) in enumerate(batches):
                 if bu.numel() == 0:
                     # the reference's loop on an empty batch: mean of nothing; here: a step with zero gradients
                     for p in model.parameters():
@@ -502,23 +509,29 @@ def test_fused_step_equals_autograd_route(device, tmp_path, batch, fraction, opt
                 loss.backward()
                 opt.step()
                 losses.append(float(loss.item()))
-        out[route] = (losses, {k: p.detach().clone() for k, p in model.named_parameters()},
-                      {k: (opt.state[p]["step"], opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone())
-                       for k, p in model.named_parameters()})
+                if j == 0:
+                    first[route] = snapshot()
+        out[route] = (losses,) + snapshot()
+    # after ONE step from the same parameters the two routes differ by the order of the float atomics only: the
+    # moments (linear / quadratic in the gradients) agree to rounding of the summed terms; a parameter element
+    # whose gradient is at the noise level may take its +-lr step in the other direction (m / sqrt(v) = +-1 at t = 1)
+    (pa1, sa1), (pb1, sb1) = first["fused"], first["autograd"]
+    for k in pa1:
+        for which, a_, b_ in (("m", sa1[k][1], sb1[k][1]), ("v", sa1[k][2], sb1[k][2])):
+            assert float((a_ - b_).norm()) <= 1e-5 * float(b_.norm()) + 1e-30, (which, k)
+            assert float((a_ - b_).abs().max()) <= 1e-4 * float(b_.abs().max()) + 1e-30, (which, k)
+        err = (pa1[k] - pb1[k]).abs()
+        assert float((err <= 1e-6 + 1e-5 * pb1[k].abs()).float().mean()) >= 0.999, k
+        assert float(err.max()) <= 2.1 * 2e-3, k
+    # after six steps the trajectories have drifted by what those elements feed back: losses to 2e-5, step counts equal,
+    # at least 99.8 % of every parameter tensor inside 2 % of the travel lr x steps, nothing beyond 10 % of it
     (la, pa, sa), (lb, pb, sb) = out["fused"], out["autograd"]
     np.testing.assert_allclose(la[0], lb[0], rtol=3e-7)     # the same scores; the batch mean summed in another order
     np.testing.assert_allclose(la, lb, rtol=2e-5)
+    travel = 2e-3 * 6
     for k in pa:
-        # parameters: where a gradient cancels to the order of Adam's eps, m / sqrt(v) turns the summation-order noise
-        # of the float atomics into a few per cent of lr per step — allowed on the parameters (2 % of
-        # lr x steps), never on the moments, which are linear in the gradients
-        torch.testing.assert_close(pa[k], pb[k], rtol=1e-3, atol=0.02 * 2e-3 * 6, msg=lambda m: f"{k}: {m}")
         assert sa[k][0] == sb[k][0] == 6
-        # the moments are linear (m) / quadratic (v) in the gradients: the two routes' gradients differ by the order of
-        # the float atomics only, i.e. by rounding relative to the terms that were SUMMED (an element that cancels to
-        # 1e-7 out of terms of 1e-4 carries 1e-9 .. 1e-7 of noise) — so the bar is on the tensor: relative
-        # Frobenius error 1e-4, no element off by more than 0.5 % of the largest
-        for which, a_, b_ in (("m", sa[k][1], sb[k][1]), ("v", sa[k][2], sb[k][2])):
-            scale = float(b_.abs().max())
-            assert float((a_ - b_).norm()) <= 1e-4 * float(b_.norm()) + 1e-30, (which, k)
-            assert float((a_ - b_).abs().max()) <= 5e-3 * scale + 1e-30, (which, k)
+        err = (pa[k] - pb[k]).abs()
+        assert float((err <= 1e-3 * pb[k].abs() + 0.02 * travel).float().mean()) >= 0.998, k
+        assert float(err.max()) <= 0.1 * travel, (k, float(err.max()))
+        assert float((sa[k][1] - sb[k][1]).norm()) <= 2e-2 * float(sb[k][1].norm()) + 1e-30, k
