@@ -152,7 +152,12 @@ __global__ __launch_bounds__(kPartThreads) void tile_partition_kernel(
   int4* s_stage = reinterpret_cast<int4*>(s_cnt + stage_off);   // TILE records of 16 B, or 2 TILE of 8 B
   constexpr int TILE = kPartThreads * PT;
   const int side = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-  if (side == 0 && tile == 0 && tid < 2) split_counters[tid] = 0;     // {tasks, scratch slots} of this batch
+  // the split block of this batch starts clean: no tasks, no slots, every item bucket whole (the user pass's sizing
+  // workgroups overwrite it; an item pass run without them must not meet the previous batch's parts)
+  if (side == 0 && tile == 0) {
+    if (tid < 2) split_counters[tid] = 0;
+    for (int i = tid; i < nbI; i += kPartThreads) split_counters[4 + i] = 1;
+  }
   const int nb = side ? nbI : nbU;
   const int shift = side ? shiftI : shiftU;
   const int rmask = (1 << shift) - 1;

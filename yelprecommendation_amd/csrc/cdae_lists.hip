@@ -68,14 +68,19 @@ __global__ __launch_bounds__(kListThreads) void cdae_train_lists_kernel(
     drop_seed = drop_seeds[r / batch_rows];
   }
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  // the row's CSR ranges are requested first and arrive while the bitmaps are cleared (they were two dependent
+  // round trips in front of everything else: with two workgroups per CU nothing hides them)
+  const int64_t u = users[r];
+  const bool user_ok = (uint64_t)u < (uint64_t)num_users;
+  int64_t lo = 0, hi = 0, lo2 = 0, hi2 = 0;
+  if (user_ok) {
+    lo = ptr[u]; hi = ptr[u + 1];
+    if (ptr2) { lo2 = ptr2[u]; hi2 = ptr2[u + 1]; }
+  }
   for (int w = tid; w < nmaps * words; w += kListThreads) s_bits[w] = 0u;
   if (tid == 0) { s_got = 0; s_bad = 0; }
   __syncthreads();
-
-  const int64_t u = users[r];
-  int64_t lo = 0, hi = 0;
-  if ((uint64_t)u < (uint64_t)num_users) { lo = ptr[u]; hi = ptr[u + 1]; }
-  else if (tid == 0 && err_flag) atomicOr(err_flag, YR_FLAG_BAD_USER);
+  if (!user_ok && tid == 0 && err_flag) atomicOr(err_flag, YR_FLAG_BAD_USER);
   for (int64_t j = lo + tid; j < hi; j += kListThreads) {
     const int64_t it = idx[j];
     if ((uint64_t)it < (uint64_t)I) {
@@ -86,8 +91,8 @@ __global__ __launch_bounds__(kListThreads) void cdae_train_lists_kernel(
       s_bad = 1;
     }
   }
-  if (ptr2 && (uint64_t)u < (uint64_t)num_users) {
-    for (int64_t j = ptr2[u] + tid; j < ptr2[u + 1]; j += kListThreads) {
+  if (ptr2) {
+    for (int64_t j = lo2 + tid; j < hi2; j += kListThreads) {
       const int64_t it = idx2[j];
       if ((uint64_t)it < (uint64_t)I) atomicOr(&s_pos[it >> 5], 1u << (it & 31));
       else s_bad = 1;
