@@ -1,6 +1,7 @@
 """Randomised check of the NGCF step against the NumPy oracle: random bipartite graphs (sizes not multiples of 32, isolated
-nodes, a few very popular items => heavy rows), D in {16, 32, 64, 128}, K in 1..3, random batch sizes; two Adam steps: loss
-and every parameter against oracle/ngcf.py.  python scratch/ngcf_fuzz.py [cases] [seed]"""
+nodes, a few very popular items => heavy rows), D in {16, 32, 64, 128}, K in 1..3, random batch sizes, random route (the
+autograd ops or the C-side step yr_ngcf_bpr_step) and random subset fraction (whole graph / default / every layer
+restricted); two Adam steps: loss and every parameter against oracle/ngcf.py.  python scratch/ngcf_fuzz.py [cases] [seed]"""
 import os, sys, tempfile
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
@@ -28,7 +29,9 @@ for c in range(cases):
     B = int(rs.choice([1, 7, 64, 513, 4096]))
     L = laplacian_scipy(u, i, r, nu, ni)
     graph = LaplacianCSR.from_scipy(L, dev, heavy_threshold=int(rs.choice([16, 128, 1024])))
-    cfg = make_config("NGCF", embed_size=d, num_orders=K, device="cuda", model_dir=tmp)
+    frac = float(rs.choice([0.0, 0.5, 1e9]))
+    fused = bool(rs.rand() < 0.5)
+    cfg = make_config("NGCF", embed_size=d, num_orders=K, device="cuda", model_dir=tmp, ngcf_subset_fraction=frac)
     torch.manual_seed(c)
     model = NGCF(cfg, nu, ni)
     with torch.no_grad():
@@ -39,18 +42,35 @@ for c in range(cases):
     model = model.to(dev)
     ref = ongcf.NGCFState(E0, W1, W2, L, nu, lr=1e-3)
     opt = Adam(model.parameters(), lr=1e-3)
+    from yelprecommendation_amd.ngcf_step import NGCFStep
+    fstep = NGCFStep(model, opt, graph, frac) if fused else None
     for step in range(2):
         bu, bp, bn = rs.randint(0, nu, B), rs.randint(0, ni, B), rs.randint(0, ni, B)
         want = float(ref.train_step(bu, bp, bn))
-        pos, neg = model.bpr_forward(*(torch.from_numpy(a.astype(np.int64)).to(dev) for a in (bu, bp, bn)), graph)
-        opt.zero_grad()
-        loss = BPRLoss()(pos, neg)
-        loss.backward()
-        opt.step()
-        np.testing.assert_allclose(loss.item(), want, rtol=5e-4, err_msg=f"case {c} loss step {step}")
-    np.testing.assert_allclose(model.embedding.weight.detach().cpu().numpy(), ref.E, rtol=3e-3, atol=3e-4, err_msg=f"case {c} E")
+        ids = [torch.from_numpy(a.astype(np.int64)).to(dev) for a in (bu, bp, bn)]
+        if fused:
+            fstep.step(*ids)
+            got = float(fstep.last_loss().item())
+        else:
+            pos, neg = model.bpr_forward(*ids, graph)
+            opt.zero_grad()
+            loss = BPRLoss()(pos, neg)
+            loss.backward()
+            opt.step()
+            got = loss.item()
+        np.testing.assert_allclose(got, want, rtol=5e-4, err_msg=f"case {c} loss step {step}")
+    if fused:
+        fstep.check()
+    def close(got, want, what):
+        # Adam moves an element by up to lr per step whatever its gradient: where the gradient is at the rounding
+        # noise of its summed terms the step may go the other way (+-lr at t = 1, 2) — allowed on a few elements
+        err = np.abs(got - want)
+        ok = err <= 3e-3 * np.abs(want) + 3e-4
+        assert ok.mean() >= 0.998, f"case {c} {what}: {ok.mean():.5f} inside the bar"
+        assert err.max() <= 2.1 * 1e-3 * 2, f"case {c} {what}: max error {err.max():.3g}"
+    close(model.embedding.weight.detach().cpu().numpy(), ref.E, "E")
     for k in range(K):
-        np.testing.assert_allclose(model.W1[k].weight.detach().cpu().numpy(), ref.W1[k], rtol=3e-3, atol=3e-4, err_msg=f"case {c} W1[{k}]")
-        np.testing.assert_allclose(model.W2[k].weight.detach().cpu().numpy(), ref.W2[k], rtol=3e-3, atol=3e-4, err_msg=f"case {c} W2[{k}]")
-    print(f"case {c}: D={d} K={K} users={nu} items={ni} nnz={len(u)} heavy rows {graph.n_heavy} B={B}: ok", flush=True)
+        close(model.W1[k].weight.detach().cpu().numpy(), ref.W1[k], f"W1[{k}]")
+        close(model.W2[k].weight.detach().cpu().numpy(), ref.W2[k], f"W2[{k}]")
+    print(f"case {c}: D={d} K={K} users={nu} items={ni} nnz={len(u)} heavy rows {graph.n_heavy} B={B} {'C step' if fused else 'autograd'} fraction {frac:g}: ok", flush=True)
 print("all", cases, "cases agree")

@@ -9,6 +9,9 @@ dev = torch.device('cuda:0')
 B = int(sys.argv[1]); impl = sys.argv[2] if len(sys.argv) > 2 else "auto"
 dist = sys.argv[3] if len(sys.argv) > 3 else "synth"; steps = int(sys.argv[4]) if len(sys.argv) > 4 else 50
 d = 64
+import os
+if os.environ.get("YR_NI"):            # experiments: another catalogue size (uniform / skew ids only)
+    NI = int(os.environ["YR_NI"])
 if dist == "synth":
     gen = torch.Generator(device=dev).manual_seed(4321)
     iu, ii = make_interactions_torch(NU, NI, 47.0, seed=1234, device=dev)
