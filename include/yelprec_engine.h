@@ -292,7 +292,8 @@ int yr_ngcf_dense_bwd_weight(const float *dEout, const float *Eout, const float 
  *   costs a few waves instead of one early-exiting wave per graph row).
  * yr_ngcf_dense_{fwd,bwd_data,bwd_weight}_rows: the dense part of a layer over the rows rows[0 .. *count) instead
  *   of 0 .. n-1; max_rows (<= n) is the host's upper bound of *count and only sizes the grid (the workgroups
- *   stride over the list, so any count up to n is covered).
+ *   stride over the list, so any count up to n is covered).  zero_rows (fwd, may be NULL): an [n, D] buffer whose
+ *   listed rows are cleared by the same launch (the layer's gradient buffer: the backward pass touches no others).
  * ------------------------------------------------------------------------- */
 int yr_ngcf_frontier_mark(const int64_t *user, const int64_t *pos, const int64_t *neg, int64_t B,
                           int64_t num_users, int64_t num_items,
@@ -313,7 +314,8 @@ int yr_spmm_csr_push_rows(const int32_t *rowptr, const int32_t *col, const float
                           const int32_t *rows, const int32_t *count, int64_t max_rows, void *stream);
 int yr_ngcf_dense_fwd_rows(const float *E, const float *Z, const float *W1, const float *W2,
                            int64_t n, int D, float *Eout,
-                           const int32_t *rows, const int32_t *count, int64_t max_rows, void *stream);
+                           const int32_t *rows, const int32_t *count, int64_t max_rows, float *zero_rows,
+                           void *stream);
 int yr_ngcf_dense_bwd_data_rows(const float *dEout, const float *Eout, const float *E, const float *Z,
                                 const float *W1T, const float *W2T, int64_t n, int D, float *dZ, float *dE,
                                 const int32_t *rows, const int32_t *count, int64_t max_rows, void *stream);

@@ -48,7 +48,7 @@ SIGNATURES = {
     "yr_ngcf_frontier_expand": [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _int, _p],
     "yr_spmm_csr_subset": [_p, _p, _p, _p, _p, _i64, _int, _int, _p, _i64, _int, _p, _p, _p, _i64, _p],
     "yr_spmm_csr_push_rows": [_p, _p, _p, _p, _p, _i64, _int, _p, _p, _i64, _p],
-    "yr_ngcf_dense_fwd_rows": [_p, _p, _p, _p, _i64, _int, _p, _p, _p, _i64, _p],
+    "yr_ngcf_dense_fwd_rows": [_p, _p, _p, _p, _i64, _int, _p, _p, _p, _i64, _p, _p],
     "yr_ngcf_dense_bwd_data_rows": [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p, _p, _i64, _p],
     "yr_ngcf_dense_bwd_weight_rows": [_p, _p, _p, _p, _i64, _int, _p, _p, _p, _p, _i64, _p],
     "yr_ngcf_step_workspace_bytes": [_i64, _int, _int, _i64],

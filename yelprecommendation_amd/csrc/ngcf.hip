@@ -362,7 +362,8 @@ __global__ __launch_bounds__(kWave) void ngcf_dense_fwd_kernel(const float* __re
                                                                const float* __restrict__ W2, int n,
                                                                float* __restrict__ Eout,
                                                                const int32_t* __restrict__ rows = nullptr,
-                                                               const int32_t* __restrict__ count = nullptr) {
+                                                               const int32_t* __restrict__ count = nullptr,
+                                                               float* __restrict__ zero_rows = nullptr) {
   using T = DenseTile<D>;
   constexpr int HALF = D / 2;
   constexpr int CT = (D + 31) / 32;          // 32-column output tiles
@@ -429,6 +430,9 @@ __global__ __launch_bounds__(kWave) void ngcf_dense_fwd_kernel(const float* __re
           o.z = acc[4 * g + 2] > 0.0f ? acc[4 * g + 2] : kSlope * acc[4 * g + 2];
           o.w = acc[4 * g + 3] > 0.0f ? acc[4 * g + 3] : kSlope * acc[4 * g + 3];
           *reinterpret_cast<float4*>(Eout + out_row * D + c) = o;
+          // row-list form: the same rows of the layer's GRADIENT buffer are cleared here (the backward pass touches
+          // no others), instead of a memset of the whole buffer
+          if (SUB && zero_rows) *reinterpret_cast<float4*>(zero_rows + out_row * D + c) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
     }
@@ -705,7 +709,9 @@ __global__ __launch_bounds__(kBlock) void ngcf_frontier_mark_kernel(const int64_
   }
 }
 
-// out = in + neighbours(in): a wave per row of the input list
+// out = in + neighbours(in).  A listed row is cut into kExpandParts slices, one workgroup each (a popular item's row has
+// thousands of neighbours: with a wave per row the 96 rows of a 32-triplet batch took 8-10 us).
+constexpr int kExpandParts = 8;
 __global__ __launch_bounds__(kBlock) void ngcf_frontier_expand_kernel(const int32_t* __restrict__ rowptr,
                                                                       const int32_t* __restrict__ col,
                                                                       const int32_t* __restrict__ rows_in,
@@ -713,15 +719,15 @@ __global__ __launch_bounds__(kBlock) void ngcf_frontier_expand_kernel(const int3
                                                                       int32_t* __restrict__ flags,
                                                                       int32_t* __restrict__ rows,
                                                                       int32_t* __restrict__ count) {
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  const int cnt = *count_in;
-  for (int it = blockIdx.x * kWavesPerBlock + wave; it < cnt; it += gridDim.x * kWavesPerBlock) {
-    const int row = rows_in[it];
-    frontier_append(lane == 0 && atomicExch(flags + row, 1) == 0, row, rows, count);
-    const int lo = rowptr[row], hi = rowptr[row + 1];
-    for (int base = lo; base < hi; base += kWave) {                             // wave-uniform trip count
-      const int idx = base + lane;
-      const int j = idx < hi ? col[idx] : -1;
+  const int64_t work = (int64_t)(*count_in) * kExpandParts;
+  for (int64_t w = blockIdx.x; w < work; w += gridDim.x) {
+    const int row = rows_in[w / kExpandParts], part = (int)(w % kExpandParts);
+    if (part == 0) frontier_append(threadIdx.x == 0 && atomicExch(flags + row, 1) == 0, row, rows, count);
+    const int lo = rowptr[row], len = rowptr[row + 1] - lo;
+    const int a = lo + (int)((int64_t)len * part / kExpandParts), b = lo + (int)((int64_t)len * (part + 1) / kExpandParts);
+    for (int base = a; base < b; base += kBlock) {                              // workgroup-uniform trip count
+      const int idx = base + threadIdx.x;
+      const int j = idx < b ? col[idx] : -1;
       frontier_append(j >= 0 && atomicExch(flags + (j >= 0 ? j : 0), 1) == 0, j, rows, count);
     }
   }
@@ -832,8 +838,8 @@ extern "C" int yr_ngcf_frontier_expand(const int32_t* rowptr, const int32_t* col
   }
   if (n == 0 || max_rows_in == 0) return 0;
   if (!rowptr || !col || !rows_in || !count_in || rows_in == rows) return YR_ERR_BADARG;
-  int grid = (int)((max_rows_in + kWavesPerBlock - 1) / kWavesPerBlock);
-  if (grid > 16384) grid = 16384;
+  const int64_t g = max_rows_in * kExpandParts;
+  const int grid = (int)(g > 16384 ? 16384 : g);
   hipLaunchKernelGGL(ngcf_frontier_expand_kernel, dim3(grid), dim3(kBlock), 0, s, rowptr, col, rows_in, count_in, flags,
                      rows, count);
   return launch_status();
@@ -964,13 +970,13 @@ static int rows_args_ok(int64_t n, const int32_t* rows, const int32_t* count, in
 
 extern "C" int yr_ngcf_dense_fwd_rows(const float* E, const float* Z, const float* W1, const float* W2, int64_t n,
                                       int D, float* Eout, const int32_t* rows, const int32_t* count,
-                                      int64_t max_rows, void* stream) {
+                                      int64_t max_rows, float* zero_rows, void* stream) {
   if (!rows_args_ok(n, rows, count, max_rows)) return YR_ERR_BADARG;
   if (n == 0 || max_rows == 0) return 0;
   if (!E || !Z || !W1 || !W2 || !Eout) return YR_ERR_BADARG;
   const int grid = (int)((max_rows + 31) / 32);
   YR_NGCF_DISPATCH(D, hipLaunchKernelGGL((ngcf_dense_fwd_kernel<kD, true>), dim3(grid), dim3(kWave), 0,
-                                         (hipStream_t)stream, E, Z, W1, W2, (int)n, Eout, rows, count));
+                                         (hipStream_t)stream, E, Z, W1, W2, (int)n, Eout, rows, count, zero_rows));
   return launch_status();
 }
 

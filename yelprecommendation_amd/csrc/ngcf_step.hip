@@ -199,8 +199,9 @@ extern "C" int yr_ngcf_bpr_step(const int32_t* rowptr, const int32_t* col, const
     if (sub[k]) {
       YR_TRY(yr_spmm_csr_subset(rowptr, col, val, layer(k), Zk(k), n, D, 0, heavy_rows, n_heavy, heavy_threshold,
                                 flags(k), rows(k), counts + k, max_rows[k], stream));
+      // (the rows of this layer's gradient buffer that the backward pass will touch are cleared by the same launch)
       YR_TRY(yr_ngcf_dense_fwd_rows(layer(k), Zk(k), W1[k], W2[k], n, D, layer(k + 1), rows(k), counts + k,
-                                    max_rows[k], stream));
+                                    max_rows[k], dlayer(k + 1), stream));
     } else {
       YR_TRY(yr_spmm_csr(rowptr, col, val, layer(k), Zk(k), n, D, 0, heavy_rows, n_heavy, heavy_threshold, stream));
       YR_TRY(yr_ngcf_dense_fwd(layer(k), Zk(k), W1[k], W2[k], n, D, layer(k + 1), stream));
@@ -226,7 +227,12 @@ extern "C" int yr_ngcf_bpr_step(const int32_t* rowptr, const int32_t* col, const
   }
 
   // ---- backward (optimizer.zero_grad() = the two clears)
-  if (hipMemsetAsync(dlayer(0), 0, (size_t)((K + 1) * nd), s) != hipSuccess) return (int)hipGetLastError();
+  // gradient buffers: whole for the layers propagated on the whole graph; a restricted layer's rows were cleared
+  // by its forward launch
+  int first_sub = K;
+  for (int k = 0; k < K; ++k)
+    if (sub[k]) { first_sub = k; break; }
+  if (hipMemsetAsync(dlayer(0), 0, (size_t)((first_sub + 1) * nd), s) != hipSuccess) return (int)hipGetLastError();
   if (B > 0)
     YR_TRY(yr_ngcf_score_bwd(layer_ptrs, dlayer_ptrs, K + 1, user, pos, neg, g_pos, g_neg, B, D, num_users,
                              n - num_users, err_flag, stream));

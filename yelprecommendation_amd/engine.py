@@ -372,7 +372,7 @@ def ngcf_dense_fwd(E, Z, W1, W2, out=None, rows=None):
     if rows is not None:
         check(lib.yr_ngcf_dense_fwd_rows(_dev(E, f32, "E"), _dev(Z, f32, "Z"), _dev(W1, f32, "W1"), _dev(W2, f32, "W2"),
                                          n, d, _dev(out, f32, "Eout"), rows.rows.data_ptr(), rows.count.data_ptr(),
-                                         rows.max_rows, _stream()), "yr_ngcf_dense_fwd_rows")
+                                         rows.max_rows, None, _stream()), "yr_ngcf_dense_fwd_rows")
         return out
     check(lib.yr_ngcf_dense_fwd(_dev(E, f32, "E"), _dev(Z, f32, "Z"), _dev(W1, f32, "W1"), _dev(W2, f32, "W2"),
                                 n, d, _dev(out, f32, "Eout"), _stream()), "yr_ngcf_dense_fwd")
