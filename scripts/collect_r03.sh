@@ -20,4 +20,7 @@ YR_BENCH_REHEARSAL_ONE_GPU=1 python3 -m torch.distributed.run --nnodes=1 --nproc
 for s in 1048576:skew 1048576:uniform 65536:skew; do
   python3 scratch/step_prof.py ${s%:*} pull ${s#*:} 100 >> $out/skewed_batches.txt 2>/dev/null || exit 1
 done
+python3 scratch/emul_shard.py > $out/emulated_rank_step.txt 2>/dev/null || exit 1
+scripts/prof_ngcf_r03.sh > $out/ngcf_prof.txt 2>&1 || exit 1
+scripts/prof_cdae_valid_r03.sh 16 > $out/cdae_valid_prof.txt 2>&1 || exit 1
 echo collected
