@@ -1,4 +1,5 @@
-"""Randomised check of yr_cdae_train_lists: for random catalogue widths (ragged, up to 30 k), per-user item counts (empty
+"""Randomised check of yr_cdae_train_lists: for random catalogue widths (ragged, up to 30 k, and a few past 65,536 where a
+part is wider than one 2,048-column wave step of the emission), per-user item counts (empty
 rows, rows that want more than half of the non-positives), neg_times, dropout levels and an optional second CSR, the encoder
 list must equal what the dense route compacts from dropout_p(dense row) (same seed) and the loss list must hold every
 positive with target 1 and exactly neg_times x as many distinct non-positives with target 0.
@@ -16,8 +17,9 @@ def csr(nu, ni, counts):
     idx = np.concatenate([np.sort(rs.choice(ni, c, replace=False)) for c in counts] + [np.zeros(0)]).astype(np.int64)
     return ptr, idx
 for c in range(cases):
-    ni = int(rs.choice([rs.randint(8, 200), rs.randint(200, 3000), rs.randint(3000, 30000)]))
+    ni = int(rs.choice([rs.randint(8, 200), rs.randint(200, 3000), rs.randint(3000, 30000), rs.randint(66000, 160000)], p=[.3, .3, .3, .1]))
     nu, B = int(rs.randint(1, 80)), int(rs.randint(1, 120))
+    if ni > 30000: B = min(B, 24)
     neg_times = int(rs.choice([0, 1, 5, 9])); p = float(rs.choice([0.0, 0.3, 0.6, 0.9]))
     cap = ni // (neg_times + 1)                                              # count x (neg_times + 1) <= I: enough non-positives
     counts = np.minimum(rs.choice([0, 1, 5, 40, 400], nu, p=[.1, .2, .4, .25, .05]), cap)

@@ -517,7 +517,7 @@ def _csr(rs, nu, ni, counts):
     return ptr, idx
 
 
-@pytest.mark.parametrize("ni", [1501, 600])
+@pytest.mark.parametrize("ni", [1501, 600, 70001])          # 70,001: a part spans more than one 2,048-column wave step
 def test_train_lists_from_csr_have_the_reference_law(device, ni):
     """yr_cdae_train_lists (a training batch as lists straight from the per-user CSR): the encoder list is exactly
     what the dense route compacts from dropout_p(dense row); the loss list holds every positive (target 1) and
