@@ -20,6 +20,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) that also carries
                   "algorithmic_GBps_with_adam_bytes" = the rate with the dense-Adam bytes the step also moves (a rate, not a
                   fraction: the working set is cache resident, so an algorithmic rate can exceed the HBM peak);
                   "batch_sweep" = the same at 32 / 4,096 / 65,536 / 262,144 / one epoch;
+  "host_resident_batches": the PCIe-inclusive rate (batches start in pinned host memory; never `value`);
   "cpu_baseline": the reference's CPU op sequence (oracle/mf_torch_cpu.py) timed on this
                   host on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -518,6 +519,45 @@ def main():
                              "algorithmic_GBps": round(b * per_triplet / sec / 1e9, 1),
                              "algorithmic_GBps_with_adam_bytes": round((b * per_triplet + adam_bytes) / sec / 1e9, 1)}
         out["batch_sweep"] = sweep
+        # The boundary takes device pointers.  A caller whose batches start on the HOST (the reference's DataLoader
+        # hands over CPU int64 tensors: 24 B per triplet) pays the PCIe copy first: the same step fed from pinned host
+        # batches, copy then step on one stream, and with the copy of batch k + 1 on a second stream under step k.
+        # Reported apart: it is never `value`.
+        hb = [tuple(t.cpu().pin_memory() for t in pool[k]) for k in range(min(2, n_pool))]
+        bufs = [tuple(torch.empty_like(t, device=dev) for t in hb[0]) for _ in range(2)]
+        def host_fed(overlap, n):
+            side = torch.cuda.Stream(device=dev) if overlap else torch.cuda.current_stream()
+            ready = [torch.cuda.Event(), torch.cuda.Event()]
+            done = [torch.cuda.Event(), torch.cuda.Event()]
+            def upload(k):
+                with torch.cuda.stream(side):
+                    side.wait_event(done[k & 1])                      # the step that read this buffer last is over
+                    for d, h in zip(bufs[k & 1], hb[k % len(hb)]):
+                        d.copy_(h, non_blocking=True)
+                    ready[k & 1].record(side)
+            for e in done:
+                e.record()
+            upload(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(n):
+                if overlap and k + 1 < n:
+                    upload(k + 1)
+                torch.cuda.current_stream().wait_event(ready[k & 1])
+                step.step(*bufs[k & 1])
+                done[k & 1].record()
+                if not overlap and k + 1 < n:
+                    upload(k + 1)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+        host_fed(True, 10)
+        serial, overlapped = host_fed(False, 40), host_fed(True, 40)
+        out["host_resident_batches"] = {
+            "note": "batches start in pinned host memory (3 x int64 per triplet over PCIe); not `value`",
+            "bytes_per_step": int(3 * 8 * B),
+            "copy_then_step": {"us_per_step": round(serial * 1e6, 1), "triplets_per_s": round(B / serial, 1)},
+            "copy_under_previous_step": {"us_per_step": round(overlapped * 1e6, 1),
+                                         "triplets_per_s": round(B / overlapped, 1)}}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.mf_torch_cpu import time_steps      # CPU baseline leg only (never the product path)

@@ -7,5 +7,5 @@ for v in "$@"; do
   echo "=== variant: $v"
   lib=$("$GRAFT_REPO_ROOT/scratch/inst_build.sh" eval_topk.hip $v) || exit 1
   export YR_ENGINE_LIB="$lib"
-  (cd ../.. && python3 bench.py --workload eval 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'],'ms', d['roofline']['frac'])") || exit 1
+  (cd ../.. && python3 bench.py --workload eval 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'],'ms cold', d['roofline']['with_hint_lists']['ms'], 'ms hinted')") || exit 1
 done

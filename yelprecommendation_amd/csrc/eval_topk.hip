@@ -65,6 +65,10 @@ constexpr int kEtMaxK = 32;
 #ifndef YR_ET_SPLIT_CHUNK
 #define YR_ET_SPLIT_CHUNK 32
 #endif
+// wave priority experiments (YR_ET_PRIO): 0 none; 1 matrix phase high; 2 epilogue high; 3 a fixed level per workgroup
+#ifndef YR_ET_PRIO
+#define YR_ET_PRIO 0
+#endif
 constexpr int kEtFlushAt = YR_ET_FLUSH_AT;             // flush when some lane holds more than this
 constexpr int kEtCheckEvery = YR_ET_CHECK_EVERY;       // ... checked after this many accumulator registers
 
@@ -416,6 +420,13 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
         *reinterpret_cast<uint4*>(dst + (q / ROW16) * ROWB + 16 * (q % ROW16)) = stage[v];
     }
   };
+#if YR_ET_PRIO == 3
+  switch ((blockIdx.x + 5 * blockIdx.y) % 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+#endif
   [[maybe_unused]] long long ph_mfma = 0, ph_mask = 0, ph_epi = 0, ph_flush = 0, ph_sync = 0, ph_total = ET_CLK();
   fetch(item_lo);
   stash(s_items[0], 0);
@@ -432,6 +443,11 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
       if (item0 >= item_hi) break;                   // wave-uniform
       // ---- scores: acc[reg] = <item item0 + row(reg, h), user of this lane>
       const long long t_a = ET_CLK();
+#if YR_ET_PRIO == 1
+      __builtin_amdgcn_s_setprio(3);
+#elif YR_ET_PRIO == 2
+      __builtin_amdgcn_s_setprio(0);
+#endif
       f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (BIAS) {                                    // accumulator register 4 g + j holds item 8 g + 4 h + j of the tile
 #pragma unroll
@@ -471,6 +487,11 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
       }
 #ifdef YR_ET_STAMPS
       asm volatile("" ::"v"(acc[0]));                 // the scores have arrived
+#endif
+#if YR_ET_PRIO == 1
+      __builtin_amdgcn_s_setprio(0);
+#elif YR_ET_PRIO == 2
+      __builtin_amdgcn_s_setprio(3);
 #endif
       const long long t_b = ET_CLK();
       ph_mfma += t_b - t_a;
