@@ -527,6 +527,12 @@ int yr_mf_scores_gemm(const float *U, const float *I, const int64_t *users, int6
  * planes); skipped without room. */
 #define YR_EVAL_NO_PRESCAN 2
 #define YR_EVAL_FORCE_PRESCAN 4   /* prescan whatever the catalogue size (tests) */
+/* or-ed into mode: the sweep in its TWO-ROLE form where it exists (YR_EVAL_BF16X3, D = 64, k <= 16; ignored elsewhere):
+ * eight-wave workgroups of 256 users, one per CU; the waves of a SIMD alternate between the matrix instructions of a
+ * tile and everything else, a workgroup barrier between the intervals.  Same scores, same lists as the default form
+ * (four-wave workgroups of 128 users, three per CU); measured slower at Yelp2018 size, kept for
+ * comparisons and as the starting point for deeper catalogues. */
+#define YR_EVAL_TWO_ROLES 8
 /* hint (may be NULL): int64 [nrows, k], any k item ids per row — typically `out` of the previous evaluation of the
  * same rows (the same buffer may be passed as hint and out).  k DIFFERENT items whose scores are all >= b prove that
  * the row's k-th best score is >= b, so the lists start from the smallest hint score (lowered by more than f32

@@ -34,7 +34,10 @@ for c in range(cases):
         junk = t(rs.randint(-1, ni + 1, size=(n, k)).astype(np.int64))
         older = engine.mf_eval_topk(t(U + 0.02 * np.abs(U).mean() * rs.standard_normal(U.shape).astype(np.float32)), *args[1:], **kw)
         for name, extra in (("prescan", dict(prescan=True)), ("hint own", dict(hint=base)), ("hint older", dict(hint=older)),
-                            ("hint junk", dict(hint=junk)), ("unsliced", dict(sliced=False)), ("unsliced + hint", dict(sliced=False, hint=older))):
+                            ("hint junk", dict(hint=junk)), ("unsliced", dict(sliced=False)), ("unsliced + hint", dict(sliced=False, hint=older)),
+                            ("two roles", dict(form="two_roles", prescan=False)), ("two roles + prescan", dict(form="two_roles", prescan=True)),
+                            ("two roles + hint", dict(form="two_roles", hint=older)), ("two roles unsliced", dict(form="two_roles", sliced=False)),
+                            ("default + hint", dict(hint=older))):
             got = engine.mf_eval_topk(*args, **kw, **extra)
             assert torch.equal(got, base), (c, prec, name, d, k, nu, n, ni, dens, mv, bias is not None)
     if bias is None and mv < -1e29:

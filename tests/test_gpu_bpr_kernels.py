@@ -217,6 +217,38 @@ def test_fused_eval_topk_edge_cases(device, d):
             np.testing.assert_array_equal(p.cpu().numpy(), a)
 
 
+@pytest.mark.parametrize("ni", [20, 33, 64, 70, 97, 333, 4100, 16411])
+def test_fused_eval_two_role_form_gives_the_same_lists(device, ni):
+    """YR_EVAL_TWO_ROLES (eight-wave workgroups whose halves alternate between the matrix instructions and the rest of a
+    tile) against the default sweep: catalogues of one, two, three tiles and of several slices, ragged row counts
+    (less than one 256-row workgroup, not a multiple of it), empty / nearly full mask rows, a mask value inside the
+    score range, item bias, k below and at the list lengths, prescan and hint lists: identical lists every time."""
+    from yelprecommendation_amd import engine
+    rs = np.random.RandomState(ni)
+    d, nu = 64, 700
+    U, I = _tables(rs, nu, ni, d)
+    t = lambda a: torch.from_numpy(a).to(device)
+    bias = t((rs.standard_normal(ni) * 0.1).astype(np.float32))
+    for n in (5, 256, 300, 1100):
+        users = rs.randint(0, nu, size=n).astype(np.int64)
+        lists = []
+        for r in range(n):
+            m = 0 if r % 5 == 0 else (max(0, ni - 5) if r % 7 == 0 else rs.randint(0, min(ni, 60)))
+            lists.append(np.sort(rs.choice(ni, size=m, replace=False)))
+        ptr = np.zeros(n + 1, np.int64); ptr[1:] = np.cumsum([len(l) for l in lists])
+        idx = np.concatenate(lists).astype(np.int64)
+        args = (t(U), t(I), t(users), t(ptr), t(idx))
+        for k in (1, 4, 7, 10, 16):
+            if k >= ni:
+                continue
+            for kw in (dict(), dict(item_bias=bias), dict(mask_value=0.0), dict(mask_value=-1.0e30, item_bias=bias)):
+                want = engine.mf_eval_topk(*args, k, prescan=False, **kw)
+                for extra in (dict(prescan=False), dict(prescan=True), dict(hint=want), dict(sliced=False),
+                              dict(hint=t(rs.randint(-1, ni + 1, size=(n, k)).astype(np.int64)))):
+                    got = engine.mf_eval_topk(*args, k, form="two_roles", **kw, **extra)
+                    assert torch.equal(got, want), (ni, n, k, kw.keys(), extra.keys())
+
+
 @pytest.mark.parametrize("precision", ["bf16x3", "f32"])
 @pytest.mark.parametrize("ni,expect_slices", [(4100, 2), (16411, 8)])
 def test_fused_eval_catalogue_slices_equal_one_slice(device, ni, expect_slices, precision):

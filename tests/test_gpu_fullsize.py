@@ -158,7 +158,7 @@ def test_cdae_full_size_step_matches_oracle(device, tmp_path):
 def test_evaluation_full_size_every_form_gives_the_same_lists(device):
     """BASELINE configs[1] size (31,668 users x 38,048 items, ~47 masked items per user, top-10): the fused
     evaluation in every form — f32 matrix instruction / three-term bf16 splits, prescan on / off, hint lists (own
-    result and the result of perturbed tables), catalogue slices on / off — must give the lists of the f32
+    result and the result of perturbed tables), catalogue slices on / off, the two-role form of the sweep — must give the lists of the f32
     instruction without prescan; rows may differ between the two precisions only at float near-ties (examined one by
     one against float64 scores).  A sample of 512 users is checked against the oracle's per-user loop as well, and
     no list may hold a masked item."""
@@ -179,7 +179,9 @@ def test_evaluation_full_size_every_form_gives_the_same_lists(device):
         assert torch.equal(engine.mf_eval_topk(U, I, users, ptr, idx, k, precision="f32", prescan=prescan), base)
     split = engine.mf_eval_topk(U, I, users, ptr, idx, k, precision="bf16x3", prescan=False)
     for kw in (dict(prescan=True), dict(hint=split), dict(hint=base), dict(sliced=False),
-               dict(hint=engine.mf_eval_topk(U * 1.02 + 0.003, I, users, ptr, idx, k))):
+               dict(hint=engine.mf_eval_topk(U * 1.02 + 0.003, I, users, ptr, idx, k)),
+               dict(form="two_roles", prescan=False), dict(form="two_roles", prescan=True),
+               dict(form="two_roles", hint=base)):
         assert torch.equal(engine.mf_eval_topk(U, I, users, ptr, idx, k, precision="bf16x3", **kw), split), kw
     Un, In, pn, xn = U.cpu().numpy(), I.cpu().numpy(), ptr.cpu().numpy(), idx.cpu().numpy()
     lists = [xn[pn[r]:pn[r + 1]] for r in range(NU)]

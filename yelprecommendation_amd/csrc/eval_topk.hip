@@ -434,7 +434,9 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
   int cur = 0;
   for (int c0 = item_lo; c0 < item_hi; c0 += (int)step) {
     const bool more = c0 + step < item_hi;
+#ifndef YR_ET_EXP_NOSTAGE
     if (more) fetch(c0 + (int)step);                 // lands in the other buffer at the end of this chunk
+#endif
     const unsigned char* chunk = s_items[cur];
 
 #pragma unroll 1
@@ -588,8 +590,13 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
     const long long t_s = ET_CLK();
     // one barrier per chunk: everyone is done reading s_items[cur ^ 1] since the previous barrier,
     // so the next chunk can be written there while slower waves still read s_items[cur]
+#ifdef YR_ET_EXP_NOSTAGE     // timing experiment only (wrong results): no global loads, no LDS writes, no barrier
+#elif defined(YR_ET_EXP_NOBARRIER)   // timing experiment only (wrong results): the waves of a workgroup never wait for each other
+    if (more) stash(s_items[cur ^ 1], cur ^ 1);
+#else
     if (more) stash(s_items[cur ^ 1], cur ^ 1);
     __syncthreads();
+#endif
     ph_sync += ET_CLK() - t_s;
     cur ^= 1;
   }
@@ -630,6 +637,344 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
 #pragma unroll
     for (int e = 0; e < KK; ++e) {
       const int o = e - (KK - k);                    // behind the phantom entries
+      if (o >= 0) {
+        if (partial) {
+          TopEntry t;
+          t.s = Ls[e];
+          t.i = Li[e];
+          partial[(row * gridDim.y + blockIdx.y) * k + o] = t;
+        } else {
+          out[row * k + o] = Li[e] == 0x7fffffff ? -1 : (int64_t)Li[e];
+        }
+      }
+    }
+  }
+}
+
+// ---- the sweep as TWO ROLES per SIMD ("ping-pong") ------------------------------------------------------------------
+// A 512-thread workgroup = 256 eval users; waves w and w + 4 share a SIMD.  Waves 0-3 run ONE PHASE AHEAD of waves 4-7:
+// while one half issues the 6 D/16 matrix instructions of a tile (operands already in registers: nothing but MFMAs
+// between two barriers), the other half does everything else for ITS previous tile — mask walk, threshold test,
+// candidates, its half of the global -> LDS staging two tiles ahead, and the LDS -> register reads of its next tile —
+// so a SIMD's matrix pipe always has one wave feeding it and its vector issue always belongs to the other
+// (`MI355X_MICROARCH.md`, "Two waves per SIMD").  One workgroup per CU, 256 registers per lane to spend.
+//   interval n (between barriers n and n + 1):  waves 0-3: scores(t) in 2t, rest(t) in 2t + 1;  waves 4-7: one later
+//   tile t lives in stage t & 1: written in intervals 2t - 3 (rows 0-15, waves 0-3) and 2t - 2 (rows 16-31, waves 4-7),
+//   read in 2t - 1 and 2t; the next tile of that stage (t + 2) is written from 2t + 1 on.
+// Same instruction order per tile as mf_eval_topk_kernel<.., SPLIT>: identical scores, identical lists.
+#ifdef YR_PP_TRACE
+// -DYR_PP_TRACE: shader-clock stamps of waves 0 and 4 of workgroup (1, 0) around every interval of tiles 100..163
+__device__ long long g_pp_trace[2][64][8];
+#define PP_STAMP(slot)                                                                               \
+  if (blockIdx.x == 1 && blockIdx.y == 0 && (wave & 3) == 0 && lane == 0 && t >= 100 && t < 164)     \
+    g_pp_trace[role][t - 100][slot] = clock64()
+#else
+#define PP_STAMP(slot)
+#endif
+constexpr int kPpWaves = 8;
+constexpr int kPpThreads = kPpWaves * kWave;             // 512
+constexpr int kPpUsers = kPpWaves * kEtUsersPerWave;     // 256 per workgroup
+#ifndef YR_PP_PRIO
+#define YR_PP_PRIO 0          // experiments: 1 = the scores interval at s_setprio 3, 2 = the rest interval
+#endif
+#ifndef YR_PP_BUFCAP
+#define YR_PP_BUFCAP 6
+#endif
+
+template <int D, int KK, bool BIAS>
+__global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
+    const float* __restrict__ U, const void* __restrict__ I_any, const float* __restrict__ item_bias,
+    const int64_t* __restrict__ users, int64_t nrows, int64_t num_users, int num_items,
+    const int64_t* __restrict__ mask_ptr, const int64_t* __restrict__ mask_idx, float mask_value, int k,
+    int64_t* __restrict__ out, TopEntry* __restrict__ partial, int items_per_slice, const float* __restrict__ gmax,
+    int parts, const float* __restrict__ row_tau, int32_t* __restrict__ err_flag) {
+  constexpr int KB = D / 16;
+  constexpr int ROWB = 6 * D + 16;                      // three bf16 planes + 16: rows of a ds_read_b128 in different banks
+  constexpr int ROW16 = 3 * D / 8;                      // 16-byte units of payload per item
+  constexpr int HALF16 = 16 * ROW16;                    // ... of the 16 rows a role stages
+  constexpr int NV = (HALF16 + 255) / 256;
+  constexpr int BUFCAP = YR_PP_BUFCAP;                  // candidate slots per lane; flushed when some lane holds more than 4
+  static_assert(BUFCAP > kEtFlushAt, "candidate buffer");
+  __shared__ __attribute__((aligned(16))) unsigned char s_items[2][32 * ROWB];
+  __shared__ TopEntry s_buf[BUFCAP][kPpThreads];
+  __shared__ __attribute__((aligned(16))) float s_bias[2][BIAS ? 32 : 4];
+  const uint4* __restrict__ I16 = static_cast<const uint4*>(I_any);
+
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int role = wave >> 2;                           // wave-uniform
+  const int tr = threadIdx.x & 255;                     // thread within the role
+  const int i = lane & 31, h = lane >> 5;
+  const int64_t row = (int64_t)blockIdx.x * kPpUsers + wave * kEtUsersPerWave + i;
+  const int item_lo = blockIdx.y * items_per_slice;
+  const int item_hi = min(num_items, item_lo + items_per_slice);
+  const int T = (item_hi - item_lo + 31) / 32;          // tiles of this slice (uniform over the workgroup)
+
+  uint4 us[3][KB];                                      // B operand: the user's row, three planes
+  bool ok = row < nrows;
+  {
+    int64_t uid = ok ? users[row] : 0;
+    if (ok && (uint64_t)uid >= (uint64_t)num_users) {
+      if (err_flag) atomicOr(err_flag, YR_FLAG_BAD_USER);
+      ok = false;
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+      if (ok) {
+        lo = *reinterpret_cast<const float4*>(U + uid * D + 16 * kb + 8 * h);
+        hi = *reinterpret_cast<const float4*>(U + uid * D + 16 * kb + 8 * h + 4);
+      }
+      et_split3x8(lo, hi, us[0][kb], us[1][kb], us[2][kb]);
+    }
+  }
+
+  float Ls[KK];
+  int32_t Li[KK];
+#pragma unroll
+  for (int e = 0; e < KK; ++e) { Ls[e] = (!ok || e < KK - k) ? INFINITY : -INFINITY; Li[e] = 0x7fffffff; }
+  float tau0 = -INFINITY;
+  if (row_tau && ok) {
+    const float b = row_tau[row];
+    tau0 = b < INFINITY ? b - fmaxf(fabsf(b) * 1.0e-6f, 1.0e-30f) : 3.0e38f;
+  } else if (gmax && ok) {
+    float Tm[KK];
+#pragma unroll
+    for (int e = 0; e < KK; ++e) Tm[e] = e < KK - k ? INFINITY : -INFINITY;
+    const float4* g4 = reinterpret_cast<const float4*>(gmax + row * parts * 32);
+    for (int q = 0; q < parts * 8; ++q) {
+      const float4 g = g4[q];
+      const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = gv[j];
+#pragma unroll
+        for (int e = 0; e < KK; ++e) {
+          const bool sw = v > Tm[e];
+          const float t = Tm[e];
+          Tm[e] = sw ? v : t;
+          v = sw ? t : v;
+        }
+      }
+    }
+    const float b = Tm[KK - 1];
+    tau0 = b < INFINITY ? b - fmaxf(fabsf(b) * 1.0e-6f, 1.0e-30f) : 3.0e38f;
+  }
+  float tau = fmaxf(Ls[KK - 1], tau0);
+  int cnt = 0;
+  const bool lazy_mask = mask_value <= -3.0e38f;
+  int64_t m_cur = 0, m_end = 0;
+  int next_masked = 0x7fffffff, after_next = 0x7fffffff;
+  if (mask_ptr && row < nrows) {
+    m_cur = mask_ptr[row];
+    m_end = mask_ptr[row + 1];
+    while (m_cur < m_end && mask_idx[m_cur] < item_lo) ++m_cur;
+    if (m_cur < m_end) next_masked = (int)mask_idx[m_cur];
+    if (m_cur + 1 < m_end) after_next = (int)mask_idx[m_cur + 1];
+  }
+
+  auto flush = [&]() {
+    for (int j = 0; __ballot(j < cnt) != 0ull; ++j) {
+      const bool live = j < cnt;
+      const float cs = s_buf[j][threadIdx.x].s;
+      const int32_t ci = s_buf[j][threadIdx.x].i;
+      et_bubble<KK>(Ls, Li, cs, ci, live);
+    }
+    cnt = 0;
+    tau = fmaxf(Ls[KK - 1], tau0);
+  };
+
+  // this role's 16 rows of a tile: global -> registers (one rest phase ahead), registers -> LDS
+  uint4 stage[NV];
+  float stage_b = 0.0f;
+  auto fetch = [&](int tile) {
+    const int c0 = item_lo + 32 * tile + 16 * role;
+    if (BIAS && tr < 16) stage_b = c0 + tr < item_hi ? item_bias[c0 + tr] : 0.0f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int q = tr + v * 256;
+      const int r = q / ROW16, c = q % ROW16;
+      stage[v] = make_uint4(0u, 0u, 0u, 0u);
+      if ((HALF16 % 256 == 0 || q < HALF16) && c0 + r < item_hi) stage[v] = I16[(int64_t)(c0 + r) * ROW16 + c];
+    }
+  };
+  auto stash = [&](int tile) {
+    unsigned char* dst = s_items[tile & 1] + 16 * role * ROWB;
+    if (BIAS && tr < 16) s_bias[tile & 1][16 * role + tr] = stage_b;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int q = tr + v * 256;
+      if (HALF16 % 256 == 0 || q < HALF16)
+        *reinterpret_cast<uint4*>(dst + (q / ROW16) * ROWB + 16 * (q % ROW16)) = stage[v];
+    }
+  };
+
+  // A operand of the next tile (item row i, dims 16 kb + 8 h + j, three planes) and the accumulator's start
+  bf16x8 A[3][KB];
+  f32x16 acc;
+  auto operands = [&](int tile) {
+    const unsigned char* src = s_items[tile & 1] + i * ROWB + 16 * h;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      A[0][kb] = *reinterpret_cast<const bf16x8*>(src + 32 * kb);
+      A[1][kb] = *reinterpret_cast<const bf16x8*>(src + 2 * D + 32 * kb);
+      A[2][kb] = *reinterpret_cast<const bf16x8*>(src + 4 * D + 32 * kb);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) acc[reg] = 0.0f;
+    if (BIAS) {                                        // accumulator register 4 g + j holds item 8 g + 4 h + j of the tile
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *reinterpret_cast<const float4*>(&s_bias[tile & 1][8 * g + 4 * h]);
+        acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
+      }
+    }
+  };
+  auto scores = [&]() {                                // the small terms first, as in the four-wave kernel
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const bf16x8 u1 = __builtin_bit_cast(bf16x8, us[0][kb]);
+      const bf16x8 u2 = __builtin_bit_cast(bf16x8, us[1][kb]);
+      const bf16x8 u3 = __builtin_bit_cast(bf16x8, us[2][kb]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2][kb], u1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][kb], u3, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][kb], u2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][kb], u1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][kb], u2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][kb], u1, acc, 0, 0, 0);
+    }
+  };
+  // mask, threshold test, candidates of tile `tile` (the scores are in acc)
+  auto rest = [&](int tile) {
+    const int item0 = item_lo + 32 * tile;
+    uint32_t bits = 0;
+#ifdef YR_PP_EXP_NOWALK
+    next_masked = 0x7fffffff;
+#endif
+    while (next_masked < item0 + 32) {
+      if (next_masked >= item0) bits |= 1u << (next_masked - item0);
+      ++m_cur;
+      next_masked = after_next;
+      after_next = m_cur + 1 < m_end ? (int)mask_idx[m_cur + 1] : 0x7fffffff;
+    }
+    const uint32_t mine = bits >> (4 * h);
+    if (!lazy_mask && __ballot(bits != 0) != 0ull) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        if ((mine >> ((reg & 3) + 8 * (reg >> 2))) & 1u) acc[reg] = mask_value;
+    }
+    if (item0 + 32 > item_hi) {                        // wave-uniform: last, partial tile of the slice
+      const uint32_t beyond = (~0u << (item_hi - item0)) >> (4 * h);
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        if ((beyond >> ((reg & 3) + 8 * (reg >> 2))) & 1u) acc[reg] = -INFINITY;
+    }
+    float mx = acc[0];
+#pragma unroll
+    for (int reg = 1; reg < 16; ++reg) mx = fmaxf(mx, acc[reg]);
+#ifdef YR_PP_EXP_NOSCAN
+    asm volatile("" ::"v"(mx));
+    return;
+#endif
+    if (__ballot(mx > tau) == 0ull) return;            // no lane of the wave has a candidate in this tile
+    // The four waves of a role wait for each other every interval, so this must be short in the common case: which of
+    // the 16 scores pass (a bit each), then one candidate per lane and round, lowest register first (ascending item
+    // ids, as the strict comparison wants) — one round with thresholds from hint lists, and ONE place that flushes.
+    uint32_t pass = 0;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) pass |= acc[reg] > tau ? 1u << reg : 0u;
+    while (__ballot(pass != 0) != 0ull) {
+      if (pass != 0) {
+        const int reg = __ffs((int)pass) - 1;
+        pass &= pass - 1;
+        float sc = acc[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) sc = reg == q ? acc[q] : sc;
+        const int pos = (reg & 3) + 8 * (reg >> 2);
+        if (lazy_mask && ((mine >> pos) & 1u)) sc = mask_value;
+        if (sc > tau) {                                // (tau may have risen in a flush since `pass` was taken)
+          TopEntry c;
+          c.s = sc;
+          c.i = item0 + pos + 4 * h;
+          s_buf[cnt][threadIdx.x] = c;
+          ++cnt;
+        }
+      }
+      if (__ballot(cnt > kEtFlushAt) != 0ull) flush();
+    }
+  };
+
+  // tiles 0 and 1 into LDS, tile 2 on its way; the first operands
+  if (T > 0) { fetch(0); stash(0); }
+  if (T > 1) { fetch(1); stash(1); }
+  if (T > 2) fetch(2);
+  __syncthreads();
+  if (T > 0) operands(0);
+  if (role == 1) __syncthreads();                      // waves 4-7 run one interval behind
+#pragma unroll 1
+  for (int t = 0; t < T; ++t) {
+    PP_STAMP(0);
+#if YR_PP_PRIO == 1
+    __builtin_amdgcn_s_setprio(3);
+#elif YR_PP_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifndef YR_PP_EXP_NOMFMA     // (YR_PP_EXP_*: timing experiments only, wrong results)
+    scores();
+#endif
+#if YR_PP_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#elif YR_PP_PRIO == 2
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    PP_STAMP(1);
+    // the matrix instructions are register-only: without this the scheduler moves 23 of the 24 BELOW the barrier,
+    // into the interval that belongs to the partner's
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    PP_STAMP(2);
+#ifndef YR_PP_EXP_NOSTAGE
+    if (t + 2 < T) stash(t + 2);
+#endif
+    PP_STAMP(5);
+#ifndef YR_PP_EXP_NOREST
+    rest(t);
+#else
+    asm volatile("" ::"v"(acc));                       // (the scores stay computed)
+#endif
+    PP_STAMP(6);
+#ifndef YR_PP_EXP_NOOPERANDS
+    if (t + 1 < T) operands(t + 1);
+#endif
+    PP_STAMP(7);
+    // the global loads LAST: the mask walk waits with vmcnt(0) for its own (older) load and would wait for these too
+#ifndef YR_PP_EXP_NOSTAGE
+    if (t + 3 < T) fetch(t + 3);
+#endif
+    PP_STAMP(3);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    PP_STAMP(4);
+  }
+  if (role == 0) __syncthreads();
+  flush();
+
+  {
+    float Os[KK];
+    int32_t Oi[KK];
+#pragma unroll
+    for (int e = 0; e < KK; ++e) {
+      Os[e] = __shfl_xor(Ls[e], 32, kWave);
+      Oi[e] = __shfl_xor(Li[e], 32, kWave);
+    }
+#pragma unroll
+    for (int e = 0; e < KK; ++e) et_bubble<KK>(Ls, Li, Os[e], Oi[e], Oi[e] != 0x7fffffff);
+  }
+  if (h == 0 && row < nrows) {
+#pragma unroll
+    for (int e = 0; e < KK; ++e) {
+      const int o = e - (KK - k);
       if (o >= 0) {
         if (partial) {
           TopEntry t;
@@ -694,6 +1039,20 @@ static int et_slices(int64_t nrows, int64_t num_items) {
   return (int)(S < 1 ? 1 : S);
 }
 
+// The two-role sweep (mf_eval_topk_pp_kernel): 256-user workgroups, ONE per CU, so at most 256 of them; split form,
+// D = 64, lists up to 16 entries; on request only (YR_EVAL_TWO_ROLES: slower than the four-wave form where measured)
+static bool et_pp_wanted(int64_t nrows, int D, int k, int mode) {
+  return (mode & YR_EVAL_BF16X3) && (mode & YR_EVAL_TWO_ROLES) && D == 64 && k <= 16;
+}
+static int et_pp_slices(int64_t nrows, int64_t num_items) {
+  const int64_t rows = (nrows + kPpUsers - 1) / kPpUsers;
+  int64_t S = 256 / rows;
+  const int64_t by_items = num_items / 2048;
+  if (S > by_items) S = by_items;
+  if (S > kEtMaxSlices) S = kEtMaxSlices;
+  return (int)(S < 1 ? 1 : S);
+}
+
 // Workspace, in this order: the item planes (YR_EVAL_BF16X3), the row thresholds of hint lists, the group maxima
 // of the prescan, the partial lists
 static int64_t et_plane_bytes(int64_t num_items, int D) { return (num_items * 6 * D + 255) / 256 * 256; }
@@ -714,7 +1073,7 @@ static bool et_prescan_wanted(int64_t num_items, int k, int mode) {
   return (mode & YR_EVAL_FORCE_PRESCAN) || (num_items >= kEtPrescanMinItems && k > 4);
 }
 static bool et_mode_ok(int mode) {
-  return (mode & ~(YR_EVAL_BF16X3 | YR_EVAL_NO_PRESCAN | YR_EVAL_FORCE_PRESCAN)) == 0 &&
+  return (mode & ~(YR_EVAL_BF16X3 | YR_EVAL_NO_PRESCAN | YR_EVAL_FORCE_PRESCAN | YR_EVAL_TWO_ROLES)) == 0 &&
          (mode & (YR_EVAL_NO_PRESCAN | YR_EVAL_FORCE_PRESCAN)) != (YR_EVAL_NO_PRESCAN | YR_EVAL_FORCE_PRESCAN);
 }
 static bool et_dim_ok(int D) { return D == 16 || D == 32 || D == 64 || D == 128; }
@@ -751,6 +1110,7 @@ struct EtArgs {
   const float* row_tau; // NULL: no hint lists
   int32_t* err_flag;
   unsigned row_blocks, slices;
+  bool two_roles;       // the sweep as mf_eval_topk_pp_kernel (row blocks of 256)
 };
 
 template <int DD, int KK, bool BB, bool SS, bool PP>
@@ -769,6 +1129,20 @@ void et_launch(const EtArgs& a, hipStream_t s) {
     const int sample = std::min(kEtSampleItems, std::max(CHP, a.num_items / 8));
     const int stride = std::max(1, chunks / std::max(1, sample / CHP));
     et_launch_one<DD, 4, BB, SS, true>(a, dim3(a.row_blocks, (unsigned)a.parts), stride, s);
+  }
+  if constexpr (SS && DD == 64) {
+    if (a.two_roles) {
+      const dim3 grid2((unsigned)((a.nrows + kPpUsers - 1) / kPpUsers), a.slices);
+#define YR_ET_PP(KK)                                                                                                  \
+  hipLaunchKernelGGL((mf_eval_topk_pp_kernel<DD, KK, BB>), grid2, dim3(kPpThreads), 0, s, a.U, a.items, a.item_bias,   \
+                     a.users, a.nrows, a.num_users, a.num_items, a.mask_ptr, a.mask_idx, a.mask_value, a.k, a.out,     \
+                     a.partial, a.per, a.gmax, a.parts, a.row_tau, a.err_flag)
+      if (a.k <= 4) YR_ET_PP(4);
+      else if (a.k <= 10) YR_ET_PP(10);
+      else YR_ET_PP(16);
+#undef YR_ET_PP
+      return;
+    }
   }
   const dim3 grid(a.row_blocks, a.slices);
   if (a.k <= 4) et_launch_one<DD, 4, BB, SS, false>(a, grid, 0, s);
@@ -841,6 +1215,8 @@ extern "C" int yr_mf_eval_topk_bias(const float* U, const float* I, const float*
     ws += et_gmax_bytes(nrows, S);
     workspace_bytes -= et_gmax_bytes(nrows, S);
   }
+  const bool two_roles = et_pp_wanted(nrows, D, k, mode);
+  if (two_roles) S = std::min(S, et_pp_slices(nrows, num_items));                          // (the prescan keeps its parts)
   if (S > 1 && workspace_bytes < nrows * S * k * (int64_t)sizeof(TopEntry)) S = 1;          // no room: one slice
   int per = (int)((num_items + S - 1) / S);
   per = (per + 31) / 32 * 32;                          // whole 32-item tiles
@@ -860,6 +1236,7 @@ extern "C" int yr_mf_eval_topk_bias(const float* U, const float* I, const float*
   a.err_flag = err_flag;
   a.row_blocks = (unsigned)((nrows + kEtUsers - 1) / kEtUsers);
   a.slices = (unsigned)S;
+  a.two_roles = two_roles;
   switch (D) {
     case 16: et_launch_d<16>(a, split, s); break;
     case 32: et_launch_d<32>(a, split, s); break;
@@ -880,6 +1257,13 @@ extern "C" int yr_mf_eval_topk(const float* U, const float* I, const int64_t* us
   return yr_mf_eval_topk_bias(U, I, nullptr, users, nrows, D, num_users, num_items, mask_ptr, mask_idx, mask_value, k,
                               out, workspace, workspace_bytes, mode, hint, err_flag, stream);
 }
+
+#ifdef YR_PP_TRACE
+extern "C" int yr_debug_pp_trace(long long* host_out) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pp_trace), sizeof(long long) * 2 * 64 * 8);
+}
+#endif
 
 #ifdef YR_ET_STAMPS
 extern "C" int yr_debug_eval_phases(unsigned long long* host_out, int reset) {

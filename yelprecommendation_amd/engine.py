@@ -906,7 +906,7 @@ EVAL_MODES = {"f32": 0, "bf16x3": 1}          # YR_EVAL_F32 / YR_EVAL_BF16X3 (in
 
 
 def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALUE, out=None, sliced=True,
-                 item_bias=None, precision="bf16x3", prescan=None, hint=None):
+                 item_bias=None, precision="bf16x3", prescan=None, hint=None, form=None):
     """Fused full-catalogue scoring + mask + top-k (no score matrix).  ``mask_idx_sorted``: CSR mask
     lists with ascending ids inside each row (see :func:`sort_mask_rows`).  ``sliced=False`` withholds
     the room for the partial lists, i.e. forces the one-slice form of the kernel (tests).  ``item_bias``: scores
@@ -918,7 +918,8 @@ def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALU
     ``hint``: int64 [n, k] item ids, e.g. the result of the previous evaluation of the same rows (may be ``out``
     itself): the lists start from the smallest score among a row's k hint items, which the row's k-th best score
     cannot be below — the result does not depend on it, a good hint saves most candidate insertions and the
-    prescan launch."""
+    prescan launch.  ``form``: None = the default four-wave sweep, "two_roles" = the two-role form where it exists
+    (YR_EVAL_TWO_ROLES: same lists; comparisons)."""
     lib = _lib.load()
     nu, ni, d = _table_dims(U, I)
     n = users.numel()
@@ -930,6 +931,7 @@ def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALU
         mode |= 2                                   # YR_EVAL_NO_PRESCAN
     elif prescan:
         mode |= 4                                   # YR_EVAL_FORCE_PRESCAN
+    mode |= {None: 0, "two_roles": 8}[form]                 # YR_EVAL_TWO_ROLES
     if out is None:
         out = torch.empty((n, k), dtype=torch.int64, device=U.device)
     if hint is not None and tuple(hint.shape) != (n, k):
