@@ -527,12 +527,15 @@ int yr_mf_scores_gemm(const float *U, const float *I, const int64_t *users, int6
  * planes); skipped without room. */
 #define YR_EVAL_NO_PRESCAN 2
 #define YR_EVAL_FORCE_PRESCAN 4   /* prescan whatever the catalogue size (tests) */
-/* or-ed into mode: the sweep in its TWO-ROLE form where it exists (YR_EVAL_BF16X3, D = 64, k <= 16; ignored elsewhere):
- * eight-wave workgroups of 256 users, one per CU; the waves of a SIMD alternate between the matrix instructions of a
- * tile and everything else, a workgroup barrier between the intervals.  Same scores, same lists as the default form
- * (four-wave workgroups of 128 users, three per CU); measured slower at Yelp2018 size, kept for
- * comparisons and as the starting point for deeper catalogues. */
+/* The sweep has two forms with the same scores and the same lists.  FOUR WAVES: workgroups of 128 users, three per
+ * CU, every wave alternating between the matrix instructions and the rest of a tile.  TWO ROLES (YR_EVAL_BF16X3;
+ * D = 64 with k <= 16, D = 128 with k <= 10): eight-wave workgroups of 256 users, one per CU; the two waves of a SIMD
+ * alternate between the matrix instructions of a tile and everything else, a workgroup barrier between the
+ * intervals.  The library picks two roles at D = 128 from 2,048 rows (1.78 -> 1.39 ms at Yelp2018 size) and four
+ * waves otherwise (D = 64: 0.82 vs 1.07 ms); these flags, or-ed into mode, force one form where both exist and are
+ * ignored elsewhere (tests, comparisons; not both). */
 #define YR_EVAL_TWO_ROLES 8
+#define YR_EVAL_FOUR_WAVES 16
 /* hint (may be NULL): int64 [nrows, k], any k item ids per row — typically `out` of the previous evaluation of the
  * same rows (the same buffer may be passed as hint and out).  k DIFFERENT items whose scores are all >= b prove that
  * the row's k-th best score is >= b, so the lists start from the smallest hint score (lowered by more than f32

@@ -1,10 +1,10 @@
 """Interval timeline of the two-role evaluation sweep (library built with -DYR_PP_TRACE via scratch/inst_build.sh, YR_ENGINE_LIB set):
-shader-clock stamps of wave 0 (role 0) and wave 4 (role 1) of one workgroup over 64 tiles.  python scratch/pp_trace.py [hint]"""
+shader-clock stamps of wave 0 (role 0) and wave 4 (role 1) of one workgroup over 64 tiles.  python scratch/pp_trace.py [hint|cold] [D]"""
 import ctypes, sys, numpy as np, torch
 sys.path.insert(0, '.')
 from yelprecommendation_amd import engine, _lib
 dev = torch.device('cuda:0')
-nu, ni, d, k = 31668, 38048, 64, 10
+nu, ni, d, k = 31668, 38048, int(sys.argv[2]) if len(sys.argv) > 2 else 64, 10
 g = torch.Generator(device=dev).manual_seed(0)
 U = torch.randn(nu, d, device=dev, generator=g) * 0.1; I = torch.randn(ni, d, device=dev, generator=g) * 0.1
 users = torch.arange(nu, device=dev)
@@ -14,7 +14,7 @@ idx = torch.randint(0, ni, (int(ptr[-1]),), device=dev, generator=g)
 sidx = engine.sort_mask_rows(ptr, idx)
 top = engine.mf_eval_topk(U, I, users, ptr, sidx, k, form="two_roles")
 for _ in range(3):
-    top = engine.mf_eval_topk(U, I, users, ptr, sidx, k, form="two_roles", hint=top if len(sys.argv) > 1 else None)
+    top = engine.mf_eval_topk(U, I, users, ptr, sidx, k, form="two_roles", hint=top if len(sys.argv) > 1 and sys.argv[1] == "hint" else None)
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = (ctypes.c_longlong * (2 * 64 * 8))()

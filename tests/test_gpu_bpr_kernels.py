@@ -217,15 +217,16 @@ def test_fused_eval_topk_edge_cases(device, d):
             np.testing.assert_array_equal(p.cpu().numpy(), a)
 
 
-@pytest.mark.parametrize("ni", [20, 33, 64, 70, 97, 333, 4100, 16411])
-def test_fused_eval_two_role_form_gives_the_same_lists(device, ni):
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("ni", [20, 33, 64, 70, 97, 130, 333, 4100, 16411])
+def test_fused_eval_two_role_form_gives_the_same_lists(device, ni, d):
     """YR_EVAL_TWO_ROLES (eight-wave workgroups whose halves alternate between the matrix instructions and the rest of a
     tile) against the default sweep: catalogues of one, two, three tiles and of several slices, ragged row counts
     (less than one 256-row workgroup, not a multiple of it), empty / nearly full mask rows, a mask value inside the
     score range, item bias, k below and at the list lengths, prescan and hint lists: identical lists every time."""
     from yelprecommendation_amd import engine
-    rs = np.random.RandomState(ni)
-    d, nu = 64, 700
+    rs = np.random.RandomState(ni + d)
+    nu = 700
     U, I = _tables(rs, nu, ni, d)
     t = lambda a: torch.from_numpy(a).to(device)
     bias = t((rs.standard_normal(ni) * 0.1).astype(np.float32))
@@ -238,11 +239,11 @@ def test_fused_eval_two_role_form_gives_the_same_lists(device, ni):
         ptr = np.zeros(n + 1, np.int64); ptr[1:] = np.cumsum([len(l) for l in lists])
         idx = np.concatenate(lists).astype(np.int64)
         args = (t(U), t(I), t(users), t(ptr), t(idx))
-        for k in (1, 4, 7, 10, 16):
+        for k in (1, 4, 7, 10) + ((16,) if d == 64 else ()):                   # (D = 128: two roles up to 10 entries)
             if k >= ni:
                 continue
             for kw in (dict(), dict(item_bias=bias), dict(mask_value=0.0), dict(mask_value=-1.0e30, item_bias=bias)):
-                want = engine.mf_eval_topk(*args, k, prescan=False, **kw)
+                want = engine.mf_eval_topk(*args, k, prescan=False, form="four_waves", **kw)
                 for extra in (dict(prescan=False), dict(prescan=True), dict(hint=want), dict(sliced=False),
                               dict(hint=t(rs.randint(-1, ni + 1, size=(n, k)).astype(np.int64)))):
                     got = engine.mf_eval_topk(*args, k, form="two_roles", **kw, **extra)

@@ -181,7 +181,7 @@ def test_evaluation_full_size_every_form_gives_the_same_lists(device):
     for kw in (dict(prescan=True), dict(hint=split), dict(hint=base), dict(sliced=False),
                dict(hint=engine.mf_eval_topk(U * 1.02 + 0.003, I, users, ptr, idx, k)),
                dict(form="two_roles", prescan=False), dict(form="two_roles", prescan=True),
-               dict(form="two_roles", hint=base)):
+               dict(form="two_roles", hint=base), dict(form="four_waves", hint=base)):
         assert torch.equal(engine.mf_eval_topk(U, I, users, ptr, idx, k, precision="bf16x3", **kw), split), kw
     Un, In, pn, xn = U.cpu().numpy(), I.cpu().numpy(), ptr.cpu().numpy(), idx.cpu().numpy()
     lists = [xn[pn[r]:pn[r + 1]] for r in range(NU)]

@@ -695,9 +695,15 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
   constexpr int NV = (HALF16 + 255) / 256;
   constexpr int BUFCAP = YR_PP_BUFCAP;                  // candidate slots per lane; flushed when some lane holds more than 4
   static_assert(BUFCAP > kEtFlushAt, "candidate buffer");
-  __shared__ __attribute__((aligned(16))) unsigned char s_items[2][32 * ROWB];
+  // D = 64: all four 16-deep blocks of a tile's operands are read into registers in the rest interval (48 registers).
+  // D = 128 (eight blocks, and the user planes already hold 96 registers): two blocks in the rest interval, the others
+  // two at a time UNDER the matrix instructions of the two before; the tile is then still being read in the interval
+  // after, so it lives in a ring of three stages instead of two.
+  constexpr int PRE = KB <= 4 ? KB : 2;
+  constexpr int NBUF = PRE < KB ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) unsigned char s_items[NBUF][32 * ROWB];
   __shared__ TopEntry s_buf[BUFCAP][kPpThreads];
-  __shared__ __attribute__((aligned(16))) float s_bias[2][BIAS ? 32 : 4];
+  __shared__ __attribute__((aligned(16))) float s_bias[NBUF][BIAS ? 32 : 4];
   const uint4* __restrict__ I16 = static_cast<const uint4*>(I_any);
 
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -783,64 +789,94 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
     tau = fmaxf(Ls[KK - 1], tau0);
   };
 
-  // this role's 16 rows of a tile: global -> registers (one rest phase ahead), registers -> LDS
+  // this role's 16 rows of a tile: global -> registers (one rest phase ahead), registers -> LDS.  No branches: rows
+  // beyond the slice read its last row (rest() turns their scores into -inf), and at D = 64, where a role's 384
+  // 16-byte units are one and a half per thread, threads 128-255 repeat the second unit of threads 0-127 (same
+  // bytes to the same place from another wave).
   uint4 stage[NV];
   float stage_b = 0.0f;
+  static_assert((HALF16 % 256 == 0 || HALF16 % 256 == 128) && NV <= 3, "units per thread");
+  auto unit = [&](int v) {                              // (loop invariant: the compiler keeps it in registers)
+    const int q = tr + v * 256;
+    return (HALF16 % 256 != 0 && q >= HALF16) ? q - 128 : q;
+  };
   auto fetch = [&](int tile) {
     const int c0 = item_lo + 32 * tile + 16 * role;
-    if (BIAS && tr < 16) stage_b = c0 + tr < item_hi ? item_bias[c0 + tr] : 0.0f;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int q = tr + v * 256;
-      const int r = q / ROW16, c = q % ROW16;
-      stage[v] = make_uint4(0u, 0u, 0u, 0u);
-      if ((HALF16 % 256 == 0 || q < HALF16) && c0 + r < item_hi) stage[v] = I16[(int64_t)(c0 + r) * ROW16 + c];
-    }
+    if (BIAS) stage_b = item_bias[min(c0 + (tr & 15), item_hi - 1)];
+    auto load = [&](int v) {
+      const int q = unit(v);
+      return I16[(int64_t)min(c0 + q / ROW16, item_hi - 1) * ROW16 + q % ROW16];
+    };
+    stage[0] = load(0);                                 // (constant indices: a loop here leaves `stage` in scratch)
+    if constexpr (NV > 1) stage[1] = load(1);
+    if constexpr (NV > 2) stage[2] = load(2);
   };
   auto stash = [&](int tile) {
-    unsigned char* dst = s_items[tile & 1] + 16 * role * ROWB;
-    if (BIAS && tr < 16) s_bias[tile & 1][16 * role + tr] = stage_b;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int q = tr + v * 256;
-      if (HALF16 % 256 == 0 || q < HALF16)
-        *reinterpret_cast<uint4*>(dst + (q / ROW16) * ROWB + 16 * (q % ROW16)) = stage[v];
-    }
+    unsigned char* dst = s_items[tile % NBUF] + 16 * role * ROWB;
+    if (BIAS && tr < 16) s_bias[tile % NBUF][16 * role + tr] = stage_b;
+    auto store = [&](int v, const uint4 x) {
+      const int q = unit(v);
+      *reinterpret_cast<uint4*>(dst + (q / ROW16) * ROWB + 16 * (q % ROW16)) = x;
+    };
+    store(0, stage[0]);
+    if constexpr (NV > 1) store(1, stage[1]);
+    if constexpr (NV > 2) store(2, stage[2]);
   };
 
-  // A operand of the next tile (item row i, dims 16 kb + 8 h + j, three planes) and the accumulator's start
-  bf16x8 A[3][KB];
+  // A operand of the next tile (item row i, dims 16 kb + 8 h + j, three planes): blocks [0, PRE) here, in the rest
+  // interval; and the accumulator's start
+  bf16x8 A[2][3][PRE == KB ? KB / 2 : 2];               // two register sets of (PRE == KB ? KB / 2 : 2) blocks
+  constexpr int SETB = PRE == KB ? KB / 2 : 2;          // blocks per set
   f32x16 acc;
-  auto operands = [&](int tile) {
-    const unsigned char* src = s_items[tile & 1] + i * ROWB + 16 * h;
+  auto blocks = [&](const unsigned char* src, int set, int kb0) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      A[0][kb] = *reinterpret_cast<const bf16x8*>(src + 32 * kb);
-      A[1][kb] = *reinterpret_cast<const bf16x8*>(src + 2 * D + 32 * kb);
-      A[2][kb] = *reinterpret_cast<const bf16x8*>(src + 4 * D + 32 * kb);
+    for (int j = 0; j < SETB; ++j) {
+      A[set][0][j] = *reinterpret_cast<const bf16x8*>(src + 32 * (kb0 + j));
+      A[set][1][j] = *reinterpret_cast<const bf16x8*>(src + 2 * D + 32 * (kb0 + j));
+      A[set][2][j] = *reinterpret_cast<const bf16x8*>(src + 4 * D + 32 * (kb0 + j));
     }
+  };
+  auto operands = [&](int tile) {
+    const unsigned char* src = s_items[tile % NBUF] + i * ROWB + 16 * h;
+    blocks(src, 0, 0);
+    if constexpr (PRE == KB) blocks(src, 1, SETB);
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) acc[reg] = 0.0f;
     if (BIAS) {                                        // accumulator register 4 g + j holds item 8 g + 4 h + j of the tile
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 b4 = *reinterpret_cast<const float4*>(&s_bias[tile & 1][8 * g + 4 * h]);
+        const float4 b4 = *reinterpret_cast<const float4*>(&s_bias[tile % NBUF][8 * g + 4 * h]);
         acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
       }
     }
   };
-  auto scores = [&]() {                                // the small terms first, as in the four-wave kernel
+  auto products = [&](int set, int kb0) {              // the small terms first, as in the four-wave kernel
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const bf16x8 u1 = __builtin_bit_cast(bf16x8, us[0][kb]);
-      const bf16x8 u2 = __builtin_bit_cast(bf16x8, us[1][kb]);
-      const bf16x8 u3 = __builtin_bit_cast(bf16x8, us[2][kb]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2][kb], u1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][kb], u3, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][kb], u2, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1][kb], u1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][kb], u2, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0][kb], u1, acc, 0, 0, 0);
+    for (int j = 0; j < SETB; ++j) {
+      const bf16x8 u1 = __builtin_bit_cast(bf16x8, us[0][kb0 + j]);
+      const bf16x8 u2 = __builtin_bit_cast(bf16x8, us[1][kb0 + j]);
+      const bf16x8 u3 = __builtin_bit_cast(bf16x8, us[2][kb0 + j]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][2][j], u1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][0][j], u3, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][1][j], u2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][1][j], u1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][0][j], u2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][0][j], u1, acc, 0, 0, 0);
+    }
+  };
+  auto scores = [&](int tile) {
+    if constexpr (PRE == KB) {
+      products(0, 0);
+      products(1, SETB);
+    } else {
+      const unsigned char* src = s_items[tile % NBUF] + i * ROWB + 16 * h;
+#pragma unroll
+      for (int g = 0; g < KB / SETB; ++g) {
+        if (g + 1 < KB / SETB) blocks(src, (g + 1) & 1, SETB * (g + 1));    // the next two blocks under these products
+        __builtin_amdgcn_sched_barrier(0);
+        products(g & 1, SETB * g);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
   // mask, threshold test, candidates of tile `tile` (the scores are in acc)
@@ -919,7 +955,7 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
     __builtin_amdgcn_s_setprio(0);
 #endif
 #ifndef YR_PP_EXP_NOMFMA     // (YR_PP_EXP_*: timing experiments only, wrong results)
-    scores();
+    scores(t);
 #endif
 #if YR_PP_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
@@ -1040,9 +1076,13 @@ static int et_slices(int64_t nrows, int64_t num_items) {
 }
 
 // The two-role sweep (mf_eval_topk_pp_kernel): 256-user workgroups, ONE per CU, so at most 256 of them; split form,
-// D = 64, lists up to 16 entries; on request only (YR_EVAL_TWO_ROLES: slower than the four-wave form where measured)
+// D = 64 with lists up to 16 entries, D = 128 up to 10.  The library's rule: D = 128 from 2,048 rows (twice the matrix
+// work per tile covers the other interval; at D = 64 the four-wave form is faster: 0.82 vs 1.07 ms hinted);
+// YR_EVAL_TWO_ROLES / YR_EVAL_FOUR_WAVES force one form where both exist (tests, comparisons)
 static bool et_pp_wanted(int64_t nrows, int D, int k, int mode) {
-  return (mode & YR_EVAL_BF16X3) && (mode & YR_EVAL_TWO_ROLES) && D == 64 && k <= 16;
+  if (!(mode & YR_EVAL_BF16X3) || (mode & YR_EVAL_FOUR_WAVES)) return false;
+  if (D == 128 && k <= 10 && nrows >= 2048) return true;                      // 1.78 -> 1.39 ms hinted, 2.31 -> 1.82 cold
+  return (mode & YR_EVAL_TWO_ROLES) && ((D == 64 && k <= 16) || (D == 128 && k <= 10));
 }
 static int et_pp_slices(int64_t nrows, int64_t num_items) {
   const int64_t rows = (nrows + kPpUsers - 1) / kPpUsers;
@@ -1073,7 +1113,8 @@ static bool et_prescan_wanted(int64_t num_items, int k, int mode) {
   return (mode & YR_EVAL_FORCE_PRESCAN) || (num_items >= kEtPrescanMinItems && k > 4);
 }
 static bool et_mode_ok(int mode) {
-  return (mode & ~(YR_EVAL_BF16X3 | YR_EVAL_NO_PRESCAN | YR_EVAL_FORCE_PRESCAN | YR_EVAL_TWO_ROLES)) == 0 &&
+  return (mode & ~(YR_EVAL_BF16X3 | YR_EVAL_NO_PRESCAN | YR_EVAL_FORCE_PRESCAN | YR_EVAL_TWO_ROLES | YR_EVAL_FOUR_WAVES)) == 0 &&
+         (mode & (YR_EVAL_TWO_ROLES | YR_EVAL_FOUR_WAVES)) != (YR_EVAL_TWO_ROLES | YR_EVAL_FOUR_WAVES) &&
          (mode & (YR_EVAL_NO_PRESCAN | YR_EVAL_FORCE_PRESCAN)) != (YR_EVAL_NO_PRESCAN | YR_EVAL_FORCE_PRESCAN);
 }
 static bool et_dim_ok(int D) { return D == 16 || D == 32 || D == 64 || D == 128; }
@@ -1130,7 +1171,7 @@ void et_launch(const EtArgs& a, hipStream_t s) {
     const int stride = std::max(1, chunks / std::max(1, sample / CHP));
     et_launch_one<DD, 4, BB, SS, true>(a, dim3(a.row_blocks, (unsigned)a.parts), stride, s);
   }
-  if constexpr (SS && DD == 64) {
+  if constexpr (SS && (DD == 64 || DD == 128)) {
     if (a.two_roles) {
       const dim3 grid2((unsigned)((a.nrows + kPpUsers - 1) / kPpUsers), a.slices);
 #define YR_ET_PP(KK)                                                                                                  \
@@ -1139,7 +1180,7 @@ void et_launch(const EtArgs& a, hipStream_t s) {
                      a.partial, a.per, a.gmax, a.parts, a.row_tau, a.err_flag)
       if (a.k <= 4) YR_ET_PP(4);
       else if (a.k <= 10) YR_ET_PP(10);
-      else YR_ET_PP(16);
+      else if constexpr (DD == 64) YR_ET_PP(16);       // (D = 128 with 16-entry lists spills: not offered, see et_pp_wanted)
 #undef YR_ET_PP
       return;
     }
