@@ -677,11 +677,15 @@ constexpr int kPpUsers = kPpWaves * kEtUsersPerWave;     // 256 per workgroup
 #ifndef YR_PP_PRIO
 #define YR_PP_PRIO 0          // experiments: 1 = the scores interval at s_setprio 3, 2 = the rest interval
 #endif
+#ifndef YR_PP_TILES_D64
+#define YR_PP_TILES_D64 2     // tiles per interval at D = 64 with lists up to 10 entries (two: the matrix interval as
+                              // long as at D = 128; with 16-entry lists the second accumulator spills)
+#endif
 #ifndef YR_PP_BUFCAP
 #define YR_PP_BUFCAP 6
 #endif
 
-template <int D, int KK, bool BIAS>
+template <int D, int KK, bool BIAS, int TILES>
 __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
     const float* __restrict__ U, const void* __restrict__ I_any, const float* __restrict__ item_bias,
     const int64_t* __restrict__ users, int64_t nrows, int64_t num_users, int num_items,
@@ -691,19 +695,22 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
   constexpr int KB = D / 16;
   constexpr int ROWB = 6 * D + 16;                      // three bf16 planes + 16: rows of a ds_read_b128 in different banks
   constexpr int ROW16 = 3 * D / 8;                      // 16-byte units of payload per item
-  constexpr int HALF16 = 16 * ROW16;                    // ... of the 16 rows a role stages
+  // An interval covers TILES 32-item tiles (a "step": 32 TILES items, one accumulator per tile): two at D = 64, so that
+  // the matrix interval (48 instructions either way) is long enough to cover the partner's.
+  constexpr int MT = 32 * TILES;                        // items per step
+  constexpr int NB = KB * TILES;                        // 16-deep operand blocks per step
+  constexpr int HALF16 = MT / 2 * ROW16;                // 16-byte units of the MT / 2 rows a role stages
   constexpr int NV = (HALF16 + 255) / 256;
   constexpr int BUFCAP = YR_PP_BUFCAP;                  // candidate slots per lane; flushed when some lane holds more than 4
   static_assert(BUFCAP > kEtFlushAt, "candidate buffer");
-  // D = 64: all four 16-deep blocks of a tile's operands are read into registers in the rest interval (48 registers).
-  // D = 128 (eight blocks, and the user planes already hold 96 registers): two blocks in the rest interval, the others
-  // two at a time UNDER the matrix instructions of the two before; the tile is then still being read in the interval
-  // after, so it lives in a ring of three stages instead of two.
-  constexpr int PRE = KB <= 4 ? KB : 2;
-  constexpr int NBUF = PRE < KB ? 3 : 2;
-  __shared__ __attribute__((aligned(16))) unsigned char s_items[NBUF][32 * ROWB];
+  // Up to four blocks: all of a step's operands are read into registers in the rest interval.  Eight blocks (D = 128;
+  // D = 64 with two tiles): two in the rest interval, the others two at a time UNDER the matrix instructions of the
+  // two before; the step is then still being read in the interval after, so it lives in a ring of three stages.
+  constexpr int PRE = NB <= 4 ? NB : 2;
+  constexpr int NBUF = PRE < NB ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) unsigned char s_items[NBUF][MT * ROWB];
   __shared__ TopEntry s_buf[BUFCAP][kPpThreads];
-  __shared__ __attribute__((aligned(16))) float s_bias[NBUF][BIAS ? 32 : 4];
+  __shared__ __attribute__((aligned(16))) float s_bias[NBUF][BIAS ? MT : 4];
   const uint4* __restrict__ I16 = static_cast<const uint4*>(I_any);
 
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -713,7 +720,7 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
   const int64_t row = (int64_t)blockIdx.x * kPpUsers + wave * kEtUsersPerWave + i;
   const int item_lo = blockIdx.y * items_per_slice;
   const int item_hi = min(num_items, item_lo + items_per_slice);
-  const int T = (item_hi - item_lo + 31) / 32;          // tiles of this slice (uniform over the workgroup)
+  const int T = (item_hi - item_lo + MT - 1) / MT;      // steps of this slice (uniform over the workgroup)
 
   uint4 us[3][KB];                                      // B operand: the user's row, three planes
   bool ok = row < nrows;
@@ -801,8 +808,8 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
     return (HALF16 % 256 != 0 && q >= HALF16) ? q - 128 : q;
   };
   auto fetch = [&](int tile) {
-    const int c0 = item_lo + 32 * tile + 16 * role;
-    if (BIAS) stage_b = item_bias[min(c0 + (tr & 15), item_hi - 1)];
+    const int c0 = item_lo + MT * tile + MT / 2 * role;
+    if (BIAS) stage_b = item_bias[min(c0 + (tr & (MT / 2 - 1)), item_hi - 1)];
     auto load = [&](int v) {
       const int q = unit(v);
       return I16[(int64_t)min(c0 + q / ROW16, item_hi - 1) * ROW16 + q % ROW16];
@@ -812,8 +819,8 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
     if constexpr (NV > 2) stage[2] = load(2);
   };
   auto stash = [&](int tile) {
-    unsigned char* dst = s_items[tile % NBUF] + 16 * role * ROWB;
-    if (BIAS && tr < 16) s_bias[tile % NBUF][16 * role + tr] = stage_b;
+    unsigned char* dst = s_items[tile % NBUF] + MT / 2 * role * ROWB;
+    if (BIAS && tr < MT / 2) s_bias[tile % NBUF][MT / 2 * role + tr] = stage_b;
     auto store = [&](int v, const uint4 x) {
       const int q = unit(v);
       *reinterpret_cast<uint4*>(dst + (q / ROW16) * ROWB + 16 * (q % ROW16)) = x;
@@ -823,119 +830,145 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
     if constexpr (NV > 2) store(2, stage[2]);
   };
 
-  // A operand of the next tile (item row i, dims 16 kb + 8 h + j, three planes): blocks [0, PRE) here, in the rest
-  // interval; and the accumulator's start
-  bf16x8 A[2][3][PRE == KB ? KB / 2 : 2];               // two register sets of (PRE == KB ? KB / 2 : 2) blocks
-  constexpr int SETB = PRE == KB ? KB / 2 : 2;          // blocks per set
-  f32x16 acc;
-  auto blocks = [&](const unsigned char* src, int set, int kb0) {
+  // A operand of the next step: block b = tile b / KB of the step, dims 16 (b % KB) + 8 h + j of item row i, three
+  // planes; blocks [0, PRE) here, in the rest interval; and the accumulators' start
+  constexpr int SETB = PRE == NB ? (NB + 1) / 2 : 2;    // blocks per register set (two sets)
+  bf16x8 A[2][3][SETB];
+  f32x16 acc[TILES];
+  auto blocks = [&](const unsigned char* stage_base, int set, int b0) {
 #pragma unroll
     for (int j = 0; j < SETB; ++j) {
-      A[set][0][j] = *reinterpret_cast<const bf16x8*>(src + 32 * (kb0 + j));
-      A[set][1][j] = *reinterpret_cast<const bf16x8*>(src + 2 * D + 32 * (kb0 + j));
-      A[set][2][j] = *reinterpret_cast<const bf16x8*>(src + 4 * D + 32 * (kb0 + j));
-    }
-  };
-  auto operands = [&](int tile) {
-    const unsigned char* src = s_items[tile % NBUF] + i * ROWB + 16 * h;
-    blocks(src, 0, 0);
-    if constexpr (PRE == KB) blocks(src, 1, SETB);
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) acc[reg] = 0.0f;
-    if (BIAS) {                                        // accumulator register 4 g + j holds item 8 g + 4 h + j of the tile
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 b4 = *reinterpret_cast<const float4*>(&s_bias[tile % NBUF][8 * g + 4 * h]);
-        acc[4 * g + 0] = b4.x; acc[4 * g + 1] = b4.y; acc[4 * g + 2] = b4.z; acc[4 * g + 3] = b4.w;
+      const int b = b0 + j;
+      if (b < NB) {
+        const unsigned char* src = stage_base + (b / KB * 32 + i) * ROWB + 16 * h + 32 * (b % KB);
+        A[set][0][j] = *reinterpret_cast<const bf16x8*>(src);
+        A[set][1][j] = *reinterpret_cast<const bf16x8*>(src + 2 * D);
+        A[set][2][j] = *reinterpret_cast<const bf16x8*>(src + 4 * D);
       }
     }
   };
-  auto products = [&](int set, int kb0) {              // the small terms first, as in the four-wave kernel
+  auto operands = [&](int tile) {
+    const unsigned char* base = s_items[tile % NBUF];
+    blocks(base, 0, 0);
+    if constexpr (PRE == NB) blocks(base, 1, SETB);
+#pragma unroll
+    for (int j = 0; j < TILES; ++j) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) acc[j][reg] = 0.0f;
+      if (BIAS) {                                      // accumulator register 4 g + q holds item 8 g + 4 h + q of its tile
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b4 = *reinterpret_cast<const float4*>(&s_bias[tile % NBUF][32 * j + 8 * g + 4 * h]);
+          acc[j][4 * g + 0] = b4.x; acc[j][4 * g + 1] = b4.y; acc[j][4 * g + 2] = b4.z; acc[j][4 * g + 3] = b4.w;
+        }
+      }
+    }
+  };
+  auto products = [&](int set, int b0) {               // the small terms first, as in the four-wave kernel
 #pragma unroll
     for (int j = 0; j < SETB; ++j) {
-      const bf16x8 u1 = __builtin_bit_cast(bf16x8, us[0][kb0 + j]);
-      const bf16x8 u2 = __builtin_bit_cast(bf16x8, us[1][kb0 + j]);
-      const bf16x8 u3 = __builtin_bit_cast(bf16x8, us[2][kb0 + j]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][2][j], u1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][0][j], u3, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][1][j], u2, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][1][j], u1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][0][j], u2, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][0][j], u1, acc, 0, 0, 0);
+      const int b = b0 + j;
+      if (b < NB) {
+        const bf16x8 u1 = __builtin_bit_cast(bf16x8, us[0][b % KB]);
+        const bf16x8 u2 = __builtin_bit_cast(bf16x8, us[1][b % KB]);
+        const bf16x8 u3 = __builtin_bit_cast(bf16x8, us[2][b % KB]);
+        f32x16& c = acc[b / KB];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][2][j], u1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][0][j], u3, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][1][j], u2, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][1][j], u1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][0][j], u2, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][0][j], u1, c, 0, 0, 0);
+      }
     }
   };
   auto scores = [&](int tile) {
-    if constexpr (PRE == KB) {
+    if constexpr (PRE == NB) {
       products(0, 0);
       products(1, SETB);
     } else {
-      const unsigned char* src = s_items[tile % NBUF] + i * ROWB + 16 * h;
+      const unsigned char* base = s_items[tile % NBUF];
 #pragma unroll
-      for (int g = 0; g < KB / SETB; ++g) {
-        if (g + 1 < KB / SETB) blocks(src, (g + 1) & 1, SETB * (g + 1));    // the next two blocks under these products
+      for (int g = 0; g < NB / SETB; ++g) {
+        if (g + 1 < NB / SETB) blocks(base, (g + 1) & 1, SETB * (g + 1));   // the next two blocks under these products
         __builtin_amdgcn_sched_barrier(0);
         products(g & 1, SETB * g);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
-  // mask, threshold test, candidates of tile `tile` (the scores are in acc)
+  // mask, threshold test, candidates of step `tile` (the scores are in acc[0 .. TILES))
   auto rest = [&](int tile) {
-    const int item0 = item_lo + 32 * tile;
-    uint32_t bits = 0;
+    const int step0 = item_lo + MT * tile;
+    uint64_t bits = 0;
 #ifdef YR_PP_EXP_NOWALK
     next_masked = 0x7fffffff;
 #endif
-    while (next_masked < item0 + 32) {
-      if (next_masked >= item0) bits |= 1u << (next_masked - item0);
+    while (next_masked < step0 + MT) {
+      if (next_masked >= step0) bits |= 1ull << (next_masked - step0);
       ++m_cur;
       next_masked = after_next;
       after_next = m_cur + 1 < m_end ? (int)mask_idx[m_cur + 1] : 0x7fffffff;
     }
-    const uint32_t mine = bits >> (4 * h);
     if (!lazy_mask && __ballot(bits != 0) != 0ull) {
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg)
-        if ((mine >> ((reg & 3) + 8 * (reg >> 2))) & 1u) acc[reg] = mask_value;
-    }
-    if (item0 + 32 > item_hi) {                        // wave-uniform: last, partial tile of the slice
-      const uint32_t beyond = (~0u << (item_hi - item0)) >> (4 * h);
+      for (int j = 0; j < TILES; ++j) {
+        const uint32_t mine = (uint32_t)(bits >> (32 * j)) >> (4 * h);
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg)
-        if ((beyond >> ((reg & 3) + 8 * (reg >> 2))) & 1u) acc[reg] = -INFINITY;
+        for (int reg = 0; reg < 16; ++reg)
+          if ((mine >> ((reg & 3) + 8 * (reg >> 2))) & 1u) acc[j][reg] = mask_value;
+      }
     }
-    float mx = acc[0];
+    if (step0 + MT > item_hi) {                        // wave-uniform: last, partial step of the slice
 #pragma unroll
-    for (int reg = 1; reg < 16; ++reg) mx = fmaxf(mx, acc[reg]);
+      for (int j = 0; j < TILES; ++j) {
+        const int valid = min(32, max(0, item_hi - (step0 + 32 * j)));
+        const uint32_t beyond = (valid >= 32 ? 0u : ~0u << valid) >> (4 * h);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          if ((beyond >> ((reg & 3) + 8 * (reg >> 2))) & 1u) acc[j][reg] = -INFINITY;
+      }
+    }
+    float mx = acc[0][0];
+#pragma unroll
+    for (int j = 0; j < TILES; ++j) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) mx = fmaxf(mx, acc[j][reg]);
+    }
 #ifdef YR_PP_EXP_NOSCAN
     asm volatile("" ::"v"(mx));
     return;
 #endif
-    if (__ballot(mx > tau) == 0ull) return;            // no lane of the wave has a candidate in this tile
+    if (__ballot(mx > tau) == 0ull) return;            // no lane of the wave has a candidate in this step
     // The four waves of a role wait for each other every interval, so this must be short in the common case: which of
-    // the 16 scores pass (a bit each), then one candidate per lane and round, lowest register first (ascending item
+    // the scores pass (a bit each), then one candidate per lane and round, lowest register first (ascending item
     // ids, as the strict comparison wants) — one round with thresholds from hint lists, and ONE place that flushes.
-    uint32_t pass = 0;
+    // (Wave-uniform register masks + a uniform register index instead: the same with hints, 20-35 % slower without.)
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) pass |= acc[reg] > tau ? 1u << reg : 0u;
-    while (__ballot(pass != 0) != 0ull) {
-      if (pass != 0) {
-        const int reg = __ffs((int)pass) - 1;
-        pass &= pass - 1;
-        float sc = acc[0];
+    for (int j = 0; j < TILES; ++j) {
+      const uint32_t mine = (uint32_t)(bits >> (32 * j)) >> (4 * h);
+      uint32_t pass = 0;
 #pragma unroll
-        for (int q = 1; q < 16; ++q) sc = reg == q ? acc[q] : sc;
-        const int pos = (reg & 3) + 8 * (reg >> 2);
-        if (lazy_mask && ((mine >> pos) & 1u)) sc = mask_value;
-        if (sc > tau) {                                // (tau may have risen in a flush since `pass` was taken)
-          TopEntry c;
-          c.s = sc;
-          c.i = item0 + pos + 4 * h;
-          s_buf[cnt][threadIdx.x] = c;
-          ++cnt;
+      for (int reg = 0; reg < 16; ++reg) pass |= acc[j][reg] > tau ? 1u << reg : 0u;
+      while (__ballot(pass != 0) != 0ull) {
+        if (pass != 0) {
+          const int reg = __ffs((int)pass) - 1;
+          pass &= pass - 1;
+          float sc = acc[j][0];
+#pragma unroll
+          for (int q = 1; q < 16; ++q) sc = reg == q ? acc[j][q] : sc;
+          const int pos = (reg & 3) + 8 * (reg >> 2);
+          if (lazy_mask && ((mine >> pos) & 1u)) sc = mask_value;
+          if (sc > tau) {                              // (tau may have risen in a flush since `pass` was taken)
+            TopEntry c;
+            c.s = sc;
+            c.i = step0 + 32 * j + pos + 4 * h;
+            s_buf[cnt][threadIdx.x] = c;
+            ++cnt;
+          }
         }
+        if (__ballot(cnt > kEtFlushAt) != 0ull) flush();
       }
-      if (__ballot(cnt > kEtFlushAt) != 0ull) flush();
     }
   };
 
@@ -976,7 +1009,7 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
 #ifndef YR_PP_EXP_NOREST
     rest(t);
 #else
-    asm volatile("" ::"v"(acc));                       // (the scores stay computed)
+    asm volatile("" ::"v"(acc[0]), "v"(acc[TILES - 1]));   // (the scores stay computed)
 #endif
     PP_STAMP(6);
 #ifndef YR_PP_EXP_NOOPERANDS
@@ -1175,7 +1208,7 @@ void et_launch(const EtArgs& a, hipStream_t s) {
     if (a.two_roles) {
       const dim3 grid2((unsigned)((a.nrows + kPpUsers - 1) / kPpUsers), a.slices);
 #define YR_ET_PP(KK)                                                                                                  \
-  hipLaunchKernelGGL((mf_eval_topk_pp_kernel<DD, KK, BB>), grid2, dim3(kPpThreads), 0, s, a.U, a.items, a.item_bias,   \
+  hipLaunchKernelGGL((mf_eval_topk_pp_kernel<DD, KK, BB, (DD == 64 && KK <= 10) ? YR_PP_TILES_D64 : 1>), grid2, dim3(kPpThreads), 0, s, a.U, a.items, a.item_bias, \
                      a.users, a.nrows, a.num_users, a.num_items, a.mask_ptr, a.mask_idx, a.mask_value, a.k, a.out,     \
                      a.partial, a.per, a.gmax, a.parts, a.row_tau, a.err_flag)
       if (a.k <= 4) YR_ET_PP(4);
