@@ -432,7 +432,11 @@ def main():
     dom = max(kt, key=lambda k: kt[k][0] * kt[k][1])
     avg_us, launches, alg_bytes = kt[dom]
     achieved = alg_bytes / (avg_us * 1e-6) / 1e9
-    group_us = group[0] if group else sum(v[0] for v in kt.values())
+    # the step's kernel time = the SUM of its launches' average durations, each between its own event pair (what the
+    # rocprofv3 kernel stats of this command list); the pair around the whole group also spans the two launch gaps and
+    # the event records themselves and is reported apart ("group_span_us")
+    group_us = sum(v[0] for v in kt.values())
+    group_span_us = group[0] if group else None
     local_B = sum(t[0].numel() for t in pool) / len(pool)
     # HBM-side traffic per step from rocprofv3 PMC passes of this same command (FETCH_SIZE doubled
     # as MI355X_MICROARCH.md prescribes, + WRITE_SIZE), committed under profiles/ by
@@ -469,6 +473,7 @@ def main():
                 "fabric_frac": round(traffic / (group_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "working_set": "tables + Adam state 71 MB: Infinity-Cache resident (256 MiB); bound = gather latency, not HBM bandwidth",
                 "avg_kernel_us": round(group_us, 2), "launches": launches,
+                "group_span_us": round(group_span_us, 2) if group_span_us else None,
                 "algorithmic_bytes_per_launch": step_alg,
                 "algorithmic_GBps_with_adam_bytes": round((step_alg + adam_bytes) / (group_us * 1e-6) / 1e9, 1),
                 "dominant_kernel": {"kernel": dom, "avg_us": round(avg_us, 2), "algorithmic_bytes": alg_bytes,
@@ -511,7 +516,7 @@ def main():
                 continue
             src = torch.cat([t[0] for t in pool])[:b], torch.cat([t[1] for t in pool])[:b], torch.cat([t[2] for t in pool])[:b]
             sec, k2 = time_steps_gpu(step, tuple(t.contiguous() for t in src), 50, 10)
-            ksum = (k2["bpr_pull_step"][0] if "owner_pass_item" in k2 else sum(v[0] for v in k2.values())) * 1e-6
+            ksum = sum(v[0] for k, v in k2.items() if k != "bpr_pull_step") * 1e-6
             sweep[str(b)] = {"us_per_step": round(sec * 1e6, 1), "triplets_per_s": round(b / sec, 1),
                              "impl": step.impl.split(":")[0], "sum_kernel_us": round(ksum * 1e6, 1),
                              # rates of SURVEY 8d's algorithmic bytes (not fractions: tables + optimizer state are
