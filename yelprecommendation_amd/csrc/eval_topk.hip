@@ -847,15 +847,17 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
       }
     }
   };
-  auto operands = [&](int tile) {
+  constexpr bool STREAM = PRE < NB;                     // operands streamed under the matrix instructions (ring of 3)
+  auto first_blocks = [&](int tile) {                   // blocks [0, PRE) of step `tile` into set 0 (and 1)
     const unsigned char* base = s_items[tile % NBUF];
     blocks(base, 0, 0);
-    if constexpr (PRE == NB) blocks(base, 1, SETB);
+    if constexpr (!STREAM) blocks(base, 1, SETB);
+  };
+  // the accumulators' start: the decoder bias; without bias the first product of a tile takes the constant 0 instead
+  auto start_acc = [&](int tile) {
+    if constexpr (BIAS) {                              // accumulator register 4 g + q holds item 8 g + 4 h + q of its tile
 #pragma unroll
-    for (int j = 0; j < TILES; ++j) {
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) acc[j][reg] = 0.0f;
-      if (BIAS) {                                      // accumulator register 4 g + q holds item 8 g + 4 h + q of its tile
+      for (int j = 0; j < TILES; ++j) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float4 b4 = *reinterpret_cast<const float4*>(&s_bias[tile % NBUF][32 * j + 8 * g + 4 * h]);
@@ -873,7 +875,8 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
         const bf16x8 u2 = __builtin_bit_cast(bf16x8, us[1][b % KB]);
         const bf16x8 u3 = __builtin_bit_cast(bf16x8, us[2][b % KB]);
         f32x16& c = acc[b / KB];
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][2][j], u1, c, 0, 0, 0);
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][2][j], u1, (!BIAS && b % KB == 0) ? zero : c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][0][j], u3, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][1][j], u2, c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][1][j], u1, c, 0, 0, 0);
@@ -893,6 +896,10 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
         if (g + 1 < NB / SETB) blocks(base, (g + 1) & 1, SETB * (g + 1));   // the next two blocks under these products
         __builtin_amdgcn_sched_barrier(0);
         products(g & 1, SETB * g);
+        // in the issue slots the dependent matrix instructions leave free: the staging (branch-free: steps beyond
+        // the slice re-read its last row into stages nobody reads) and, at the end, the first blocks of the next step
+        if (g == 0) { stash(tile + 2); fetch(tile + 3); }
+        if (g == NB / SETB - 1) first_blocks(tile + 1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -977,7 +984,7 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
   if (T > 1) { fetch(1); stash(1); }
   if (T > 2) fetch(2);
   __syncthreads();
-  if (T > 0) operands(0);
+  if (T > 0) { first_blocks(0); start_acc(0); }
   if (role == 1) __syncthreads();                      // waves 4-7 run one interval behind
 #pragma unroll 1
   for (int t = 0; t < T; ++t) {
@@ -1003,7 +1010,7 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
     __builtin_amdgcn_sched_barrier(0);
     PP_STAMP(2);
 #ifndef YR_PP_EXP_NOSTAGE
-    if (t + 2 < T) stash(t + 2);
+    if (!STREAM && t + 2 < T) stash(t + 2);
 #endif
     PP_STAMP(5);
 #ifndef YR_PP_EXP_NOREST
@@ -1013,12 +1020,15 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
 #endif
     PP_STAMP(6);
 #ifndef YR_PP_EXP_NOOPERANDS
-    if (t + 1 < T) operands(t + 1);
+    if (t + 1 < T) {
+      if (!STREAM) first_blocks(t + 1);
+      start_acc(t + 1);
+    }
 #endif
     PP_STAMP(7);
     // the global loads LAST: the mask walk waits with vmcnt(0) for its own (older) load and would wait for these too
 #ifndef YR_PP_EXP_NOSTAGE
-    if (t + 3 < T) fetch(t + 3);
+    if (!STREAM && t + 3 < T) fetch(t + 3);
 #endif
     PP_STAMP(3);
     __builtin_amdgcn_sched_barrier(0);
