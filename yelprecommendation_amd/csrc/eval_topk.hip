@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
 #ifndef YR_PP_EXP_NOREST
     rest(t);
 #else
-    asm volatile("" ::"v"(acc[0]), "v"(acc[TILES - 1]));   // (the scores stay computed)
+    asm volatile("" ::"v"(acc[0][0]), "v"(acc[TILES - 1][15]));   // (the scores stay computed)
 #endif
     PP_STAMP(6);
 #ifndef YR_PP_EXP_NOOPERANDS
@@ -1119,13 +1119,15 @@ static int et_slices(int64_t nrows, int64_t num_items) {
 }
 
 // The two-role sweep (mf_eval_topk_pp_kernel): 256-user workgroups, ONE per CU, so at most 256 of them; split form,
-// D = 64 with lists up to 16 entries, D = 128 up to 10.  The library's rule: D = 128 from 2,048 rows (twice the matrix
-// work per tile covers the other interval; at D = 64 the four-wave form is faster: 0.82 vs 1.07 ms hinted);
-// YR_EVAL_TWO_ROLES / YR_EVAL_FOUR_WAVES force one form where both exist (tests, comparisons)
-static bool et_pp_wanted(int64_t nrows, int D, int k, int mode) {
+// D = 64 with lists up to 16 entries, D = 128 up to 10.  The library's rule, from 2,048 rows: D = 128 always (hinted
+// 1.78 -> 1.42 ms, cold 2.34 -> 1.78 at Yelp2018 size); D = 64 with thresholds from hint lists (k = 4 / 10 / 16:
+// 0.78 / 0.82 / 1.27 -> 0.74 / 0.80 / 1.14 ms), but not with the looser ones of the prescan (1.12 -> 1.23 ms: more
+// candidates, and every wave of a role waits for the slowest).  YR_EVAL_TWO_ROLES / YR_EVAL_FOUR_WAVES force a form.
+static bool et_pp_wanted(int64_t nrows, int D, int k, int mode, bool hinted) {
   if (!(mode & YR_EVAL_BF16X3) || (mode & YR_EVAL_FOUR_WAVES)) return false;
-  if (D == 128 && k <= 10 && nrows >= 2048) return true;                      // 1.78 -> 1.39 ms hinted, 2.31 -> 1.82 cold
-  return (mode & YR_EVAL_TWO_ROLES) && ((D == 64 && k <= 16) || (D == 128 && k <= 10));
+  const bool exists = (D == 64 && k <= 16) || (D == 128 && k <= 10);
+  if (mode & YR_EVAL_TWO_ROLES) return exists;
+  return exists && nrows >= 2048 && (D == 128 || hinted);
 }
 static int et_pp_slices(int64_t nrows, int64_t num_items) {
   const int64_t rows = (nrows + kPpUsers - 1) / kPpUsers;
@@ -1299,7 +1301,7 @@ extern "C" int yr_mf_eval_topk_bias(const float* U, const float* I, const float*
     ws += et_gmax_bytes(nrows, S);
     workspace_bytes -= et_gmax_bytes(nrows, S);
   }
-  const bool two_roles = et_pp_wanted(nrows, D, k, mode);
+  const bool two_roles = et_pp_wanted(nrows, D, k, mode, a.row_tau != nullptr);
   if (two_roles) S = std::min(S, et_pp_slices(nrows, num_items));                          // (the prescan keeps its parts)
   if (S > 1 && workspace_bytes < nrows * S * k * (int64_t)sizeof(TopEntry)) S = 1;          // no room: one slice
   int per = (int)((num_items + S - 1) / S);
