@@ -531,10 +531,10 @@ int yr_mf_scores_gemm(const float *U, const float *I, const int64_t *users, int6
  * CU, every wave alternating between the matrix instructions and the rest of a tile.  TWO ROLES (YR_EVAL_BF16X3;
  * D = 64 with k <= 16, D = 128 with k <= 10): eight-wave workgroups of 256 users, one per CU; the two waves of a SIMD
  * alternate between the matrix instructions of a tile and everything else, a workgroup barrier between the
- * intervals.  The library picks, from 2,048 rows: two roles at D = 128 (1.78 -> 1.42 ms at Yelp2018 size) and at
- * D = 64 when the thresholds come from hint lists (0.82 -> 0.80 ms at k = 10, 1.27 -> 1.14 at k = 16); four waves
- * otherwise.  These flags, or-ed into mode, force one form where both exist and are ignored elsewhere (tests,
- * comparisons; not both). */
+ * intervals.  The library picks, from 2,048 rows: two roles at D = 128 (sweep 1.90 -> 1.55 ms at Yelp2018 size) and
+ * at D = 64 for 16-entry lists with thresholds from hint lists (1.27 -> 1.14 ms); four waves otherwise (D = 64, k <= 10:
+ * equal with hints, 10 % faster without).  These flags, or-ed into mode, force one form where both exist and are
+ * ignored elsewhere (tests, comparisons; not both). */
 #define YR_EVAL_TWO_ROLES 8
 #define YR_EVAL_FOUR_WAVES 16
 /* hint (may be NULL): int64 [nrows, k], any k item ids per row — typically `out` of the previous evaluation of the

@@ -1119,15 +1119,16 @@ static int et_slices(int64_t nrows, int64_t num_items) {
 }
 
 // The two-role sweep (mf_eval_topk_pp_kernel): 256-user workgroups, ONE per CU, so at most 256 of them; split form,
-// D = 64 with lists up to 16 entries, D = 128 up to 10.  The library's rule, from 2,048 rows: D = 128 always (hinted
-// 1.78 -> 1.42 ms, cold 2.34 -> 1.78 at Yelp2018 size); D = 64 with thresholds from hint lists (k = 4 / 10 / 16:
-// 0.78 / 0.82 / 1.27 -> 0.74 / 0.80 / 1.14 ms), but not with the looser ones of the prescan (1.12 -> 1.23 ms: more
-// candidates, and every wave of a role waits for the slowest).  YR_EVAL_TWO_ROLES / YR_EVAL_FOUR_WAVES force a form.
+// D = 64 with lists up to 16 entries, D = 128 up to 10.  The library's rule, from 2,048 rows: D = 128 always (sweep
+// 1.90 -> 1.55 ms hinted, whole call cold 2.34 -> 1.78 at Yelp2018 size); D = 64 with 16-entry lists and thresholds
+// from hint lists (1.27 -> 1.14 ms); at D = 64 with lists up to 10 entries the two forms take the same time with
+// hints (0.80 vs 0.82 ms) and the four-wave form is faster without (1.12 vs 1.23: more candidates, and every wave of
+// a role waits for the slowest), so it stays.  YR_EVAL_TWO_ROLES / YR_EVAL_FOUR_WAVES force a form.
 static bool et_pp_wanted(int64_t nrows, int D, int k, int mode, bool hinted) {
   if (!(mode & YR_EVAL_BF16X3) || (mode & YR_EVAL_FOUR_WAVES)) return false;
   const bool exists = (D == 64 && k <= 16) || (D == 128 && k <= 10);
   if (mode & YR_EVAL_TWO_ROLES) return exists;
-  return exists && nrows >= 2048 && (D == 128 || hinted);
+  return exists && nrows >= 2048 && (D == 128 || (hinted && k > 10));
 }
 static int et_pp_slices(int64_t nrows, int64_t num_items) {
   const int64_t rows = (nrows + kPpUsers - 1) / kPpUsers;

@@ -919,7 +919,7 @@ def mf_eval_topk(U, I, users, mask_ptr, mask_idx_sorted, k, mask_value=MASK_VALU
     itself): the lists start from the smallest score among a row's k hint items, which the row's k-th best score
     cannot be below — the result does not depend on it, a good hint saves most candidate insertions and the
     prescan launch.  ``form``: None = the library's rule (from 2,048 rows the two-role sweep at D = 128, and at D = 64
-    when a hint gives the thresholds; the four-wave sweep otherwise), "two_roles" / "four_waves" = that form where both exist (YR_EVAL_TWO_ROLES / YR_EVAL_FOUR_WAVES:
+    for k > 10 when a hint gives the thresholds; the four-wave sweep otherwise), "two_roles" / "four_waves" = that form where both exist (YR_EVAL_TWO_ROLES / YR_EVAL_FOUR_WAVES:
     same lists; tests and comparisons)."""
     lib = _lib.load()
     nu, ni, d = _table_dims(U, I)
