@@ -266,6 +266,108 @@ __host__ __device__ constexpr int et_chunk_items(int D, int KK, bool split) {
 // k-th best score over the whole catalogue, and every list of the user (both half-waves, every slice) starts with
 // a threshold just below it instead of -inf.  What the lists then never see could not have ended in the top k.
 // (Hint lists — et_hint_bound_kernel, row_tau — give a bound of the same kind from k rescored items instead.)
+// ---- pieces both forms of the sweep share (forceinline: the lists and planes stay in the callers' registers) ----
+
+// the user id of this lane's row (false: a row beyond the input or a bad id -> flagged, an all-zero operand)
+__device__ __forceinline__ bool et_row_user(const int64_t* __restrict__ users, int64_t row, int64_t nrows,
+                                            int64_t num_users, int32_t* __restrict__ err_flag, int64_t& uid) {
+  bool ok = row < nrows;
+  uid = ok ? users[row] : 0;
+  if (ok && (uint64_t)uid >= (uint64_t)num_users) {
+    if (err_flag) atomicOr(err_flag, YR_FLAG_BAD_USER);
+    ok = false;
+  }
+  return ok;
+}
+
+// B operand of the split form: dims 16 kb + 8 h + j of every 16-deep block kb of the user's row, three bf16 planes
+template <int D>
+__device__ __forceinline__ void et_user_planes(const float* __restrict__ U, int64_t uid, bool ok, int h,
+                                               uint4 (&us)[3][D / 16]) {
+#pragma unroll
+  for (int kb = 0; kb < D / 16; ++kb) {
+    float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+    if (ok) {
+      lo = *reinterpret_cast<const float4*>(U + uid * D + 16 * kb + 8 * h);
+      hi = *reinterpret_cast<const float4*>(U + uid * D + 16 * kb + 8 * h + 4);
+    }
+    et_split3x8(lo, hi, us[0][kb], us[1][kb], us[2][kb]);
+  }
+}
+
+// The private list's start and the floor of its threshold.  Only the top k leave the kernel: the first KK - k places
+// are held by phantom entries (+inf, no item), so the list's last score — the threshold — is the lane's k-th best,
+// not its KK-th (+inf everywhere: nothing enters).  The floor comes from hint lists (row_tau) or from the prescan's
+// group maxima (gmax: the k-th largest of them), strictly below the bound: scores equal to it must pass the strict test.
+template <int KK>
+__device__ __forceinline__ float et_start_lists(float (&Ls)[KK], int32_t (&Li)[KK], int k, bool ok, int64_t row,
+                                                const float* __restrict__ row_tau, const float* __restrict__ gmax,
+                                                int parts) {
+#pragma unroll
+  for (int e = 0; e < KK; ++e) { Ls[e] = (!ok || e < KK - k) ? INFINITY : -INFINITY; Li[e] = 0x7fffffff; }
+  float tau0 = -INFINITY;
+  if (row_tau && ok) {
+    const float b = row_tau[row];
+    tau0 = b < INFINITY ? b - fmaxf(fabsf(b) * 1.0e-6f, 1.0e-30f) : 3.0e38f;
+  } else if (gmax && ok) {
+    float T[KK];                                     // the largest group maxima of this lane's user, descending
+#pragma unroll
+    for (int e = 0; e < KK; ++e) T[e] = e < KK - k ? INFINITY : -INFINITY;   // the k-th largest ends up last (see Ls)
+    const float4* g4 = reinterpret_cast<const float4*>(gmax + row * parts * 32);
+    for (int q = 0; q < parts * 8; ++q) {
+      const float4 g = g4[q];
+      const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = gv[j];
+#pragma unroll
+        for (int e = 0; e < KK; ++e) {
+          const bool sw = v > T[e];
+          const float t = T[e];
+          T[e] = sw ? v : t;
+          v = sw ? t : v;
+        }
+      }
+    }
+    const float b = T[KK - 1];                       // -FLT_MAX and -inf give -inf
+    tau0 = b < INFINITY ? b - fmaxf(fabsf(b) * 1.0e-6f, 1.0e-30f) : 3.0e38f;
+  }
+  return tau0;
+}
+
+// the two half-waves' lists of the same user (lane i <-> lane i + 32) merged, then the top k written: to the slice's
+// partial lists, or to `out` (-1 for an empty place)
+template <int KK>
+__device__ __forceinline__ void et_finish_lists(float (&Ls)[KK], int32_t (&Li)[KK], int k, int h, int64_t row,
+                                                int64_t nrows, TopEntry* __restrict__ partial,
+                                                int64_t* __restrict__ out) {
+  float Os[KK];
+  int32_t Oi[KK];
+#pragma unroll
+  for (int e = 0; e < KK; ++e) {
+    Os[e] = __shfl_xor(Ls[e], 32, kWave);
+    Oi[e] = __shfl_xor(Li[e], 32, kWave);
+  }
+#pragma unroll
+  for (int e = 0; e < KK; ++e) et_bubble<KK>(Ls, Li, Os[e], Oi[e], Oi[e] != 0x7fffffff);
+  if (h == 0 && row < nrows) {
+#pragma unroll
+    for (int e = 0; e < KK; ++e) {
+      const int o = e - (KK - k);                    // behind the phantom entries
+      if (o >= 0) {
+        if (partial) {
+          TopEntry t;
+          t.s = Ls[e];
+          t.i = Li[e];
+          partial[(row * gridDim.y + blockIdx.y) * k + o] = t;
+        } else {
+          out[row * k + o] = Li[e] == 0x7fffffff ? -1 : (int64_t)Li[e];
+        }
+      }
+    }
+  }
+}
+
 template <int D, int KK, bool BIAS, bool SPLIT, bool PRESCAN>
 __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
     const float* __restrict__ U, const void* __restrict__ I_any, const float* __restrict__ item_bias,
@@ -303,69 +405,24 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
   // B operand: this lane's half of its user's row (zeros for rows beyond the input / bad ids) — f32: dims
   // [h D/2, (h+1) D/2); SPLIT: dims 16 kb + 8 h + j of every 16-deep block kb, three planes
   float ub[SPLIT ? 1 : HALF];
-  uint4 us[SPLIT ? 3 : 1][SPLIT ? KB : 1];
-  bool ok = row < nrows;
-  {
-    int64_t uid = ok ? users[row] : 0;
-    if (ok && (uint64_t)uid >= (uint64_t)num_users) {
-      if (err_flag) atomicOr(err_flag, YR_FLAG_BAD_USER);
-      ok = false;
-    }
-    if constexpr (SPLIT) {
+  uint4 us[3][KB];                                   // (unused, and removed by the compiler, in the f32 form)
+  int64_t uid;
+  const bool ok = et_row_user(users, row, nrows, num_users, err_flag, uid);
+  if constexpr (SPLIT) {
+    et_user_planes<D>(U, uid, ok, h, us);
+  } else {
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-        if (ok) {
-          lo = *reinterpret_cast<const float4*>(U + uid * D + 16 * kb + 8 * h);
-          hi = *reinterpret_cast<const float4*>(U + uid * D + 16 * kb + 8 * h + 4);
-        }
-        et_split3x8(lo, hi, us[0][kb], us[1][kb], us[2][kb]);
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < HALF / 4; ++q) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v = *reinterpret_cast<const float4*>(U + uid * D + h * HALF + 4 * q);
-        ub[4 * q + 0] = v.x; ub[4 * q + 1] = v.y; ub[4 * q + 2] = v.z; ub[4 * q + 3] = v.w;
-      }
+    for (int q = 0; q < HALF / 4; ++q) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float4*>(U + uid * D + h * HALF + 4 * q);
+      ub[4 * q + 0] = v.x; ub[4 * q + 1] = v.y; ub[4 * q + 2] = v.z; ub[4 * q + 3] = v.w;
     }
   }
 
   // private list, threshold, buffer fill and mask cursor
   float Ls[KK];
   int32_t Li[KK];
-#pragma unroll
-  // Only the top k leave the kernel: the first KK - k places are held by phantom entries (+inf, no item), so the
-  // list's last score — the threshold — is the lane's k-th best, not its KK-th.  (+inf everywhere: nothing enters.)
-  for (int e = 0; e < KK; ++e) { Ls[e] = (!ok || e < KK - k) ? INFINITY : -INFINITY; Li[e] = 0x7fffffff; }
-  float tau0 = -INFINITY;                            // the floor of the threshold: from hint lists or from the prescan
-  if (!PRESCAN && row_tau && ok) {
-    const float b = row_tau[row];                    // strictly below the bound, as for the prescan's
-    tau0 = b < INFINITY ? b - fmaxf(fabsf(b) * 1.0e-6f, 1.0e-30f) : 3.0e38f;
-  } else if (!PRESCAN && gmax && ok) {
-    float T[KK];                                     // the largest group maxima of this lane's user, descending
-#pragma unroll
-    for (int e = 0; e < KK; ++e) T[e] = e < KK - k ? INFINITY : -INFINITY;   // the k-th largest ends up last (see Ls)
-    const float4* g4 = reinterpret_cast<const float4*>(gmax + row * parts * 32);
-    for (int q = 0; q < parts * 8; ++q) {
-      const float4 g = g4[q];
-      const float gv[4] = {g.x, g.y, g.z, g.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v = gv[j];
-#pragma unroll
-        for (int e = 0; e < KK; ++e) {
-          const bool sw = v > T[e];
-          const float t = T[e];
-          T[e] = sw ? v : t;
-          v = sw ? t : v;
-        }
-      }
-    }
-    // strictly below the bound (scores equal to it must pass the strict test); -FLT_MAX and -inf give -inf
-    const float b = T[KK - 1];
-    tau0 = b < INFINITY ? b - fmaxf(fabsf(b) * 1.0e-6f, 1.0e-30f) : 3.0e38f;
-  }
+  const float tau0 = et_start_lists<KK>(Ls, Li, k, ok, row, PRESCAN ? nullptr : row_tau, PRESCAN ? nullptr : gmax, parts);
   float tau = fmaxf(Ls[KK - 1], tau0);
   float gm[PRESCAN ? 16 : 1];                        // PRESCAN: running maxima of the 16 accumulator registers
 #pragma unroll
@@ -621,34 +678,7 @@ __global__ __launch_bounds__(kEtThreads) void mf_eval_topk_kernel(
   }
 #endif
 
-  // ---- merge the two half-waves' lists of the same user (lane i <-> lane i + 32)
-  {
-    float Os[KK];
-    int32_t Oi[KK];
-#pragma unroll
-    for (int e = 0; e < KK; ++e) {
-      Os[e] = __shfl_xor(Ls[e], 32, kWave);
-      Oi[e] = __shfl_xor(Li[e], 32, kWave);
-    }
-#pragma unroll
-    for (int e = 0; e < KK; ++e) et_bubble<KK>(Ls, Li, Os[e], Oi[e], Oi[e] != 0x7fffffff);
-  }
-  if (h == 0 && row < nrows) {
-#pragma unroll
-    for (int e = 0; e < KK; ++e) {
-      const int o = e - (KK - k);                    // behind the phantom entries
-      if (o >= 0) {
-        if (partial) {
-          TopEntry t;
-          t.s = Ls[e];
-          t.i = Li[e];
-          partial[(row * gridDim.y + blockIdx.y) * k + o] = t;
-        } else {
-          out[row * k + o] = Li[e] == 0x7fffffff ? -1 : (int64_t)Li[e];
-        }
-      }
-    }
-  }
+  et_finish_lists<KK>(Ls, Li, k, h, row, nrows, partial, out);
 }
 
 // ---- the sweep as TWO ROLES per SIMD ("ping-pong") ------------------------------------------------------------------
@@ -723,55 +753,12 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
   const int T = (item_hi - item_lo + MT - 1) / MT;      // steps of this slice (uniform over the workgroup)
 
   uint4 us[3][KB];                                      // B operand: the user's row, three planes
-  bool ok = row < nrows;
-  {
-    int64_t uid = ok ? users[row] : 0;
-    if (ok && (uint64_t)uid >= (uint64_t)num_users) {
-      if (err_flag) atomicOr(err_flag, YR_FLAG_BAD_USER);
-      ok = false;
-    }
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-      if (ok) {
-        lo = *reinterpret_cast<const float4*>(U + uid * D + 16 * kb + 8 * h);
-        hi = *reinterpret_cast<const float4*>(U + uid * D + 16 * kb + 8 * h + 4);
-      }
-      et_split3x8(lo, hi, us[0][kb], us[1][kb], us[2][kb]);
-    }
-  }
-
+  int64_t uid;
+  const bool ok = et_row_user(users, row, nrows, num_users, err_flag, uid);
+  et_user_planes<D>(U, uid, ok, h, us);
   float Ls[KK];
   int32_t Li[KK];
-#pragma unroll
-  for (int e = 0; e < KK; ++e) { Ls[e] = (!ok || e < KK - k) ? INFINITY : -INFINITY; Li[e] = 0x7fffffff; }
-  float tau0 = -INFINITY;
-  if (row_tau && ok) {
-    const float b = row_tau[row];
-    tau0 = b < INFINITY ? b - fmaxf(fabsf(b) * 1.0e-6f, 1.0e-30f) : 3.0e38f;
-  } else if (gmax && ok) {
-    float Tm[KK];
-#pragma unroll
-    for (int e = 0; e < KK; ++e) Tm[e] = e < KK - k ? INFINITY : -INFINITY;
-    const float4* g4 = reinterpret_cast<const float4*>(gmax + row * parts * 32);
-    for (int q = 0; q < parts * 8; ++q) {
-      const float4 g = g4[q];
-      const float gv[4] = {g.x, g.y, g.z, g.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v = gv[j];
-#pragma unroll
-        for (int e = 0; e < KK; ++e) {
-          const bool sw = v > Tm[e];
-          const float t = Tm[e];
-          Tm[e] = sw ? v : t;
-          v = sw ? t : v;
-        }
-      }
-    }
-    const float b = Tm[KK - 1];
-    tau0 = b < INFINITY ? b - fmaxf(fabsf(b) * 1.0e-6f, 1.0e-30f) : 3.0e38f;
-  }
+  const float tau0 = et_start_lists<KK>(Ls, Li, k, ok, row, row_tau, gmax, parts);
   float tau = fmaxf(Ls[KK - 1], tau0);
   int cnt = 0;
   const bool lazy_mask = mask_value <= -3.0e38f;
@@ -1038,34 +1025,7 @@ __global__ __launch_bounds__(kPpThreads) void mf_eval_topk_pp_kernel(
   }
   if (role == 0) __syncthreads();
   flush();
-
-  {
-    float Os[KK];
-    int32_t Oi[KK];
-#pragma unroll
-    for (int e = 0; e < KK; ++e) {
-      Os[e] = __shfl_xor(Ls[e], 32, kWave);
-      Oi[e] = __shfl_xor(Li[e], 32, kWave);
-    }
-#pragma unroll
-    for (int e = 0; e < KK; ++e) et_bubble<KK>(Ls, Li, Os[e], Oi[e], Oi[e] != 0x7fffffff);
-  }
-  if (h == 0 && row < nrows) {
-#pragma unroll
-    for (int e = 0; e < KK; ++e) {
-      const int o = e - (KK - k);
-      if (o >= 0) {
-        if (partial) {
-          TopEntry t;
-          t.s = Ls[e];
-          t.i = Li[e];
-          partial[(row * gridDim.y + blockIdx.y) * k + o] = t;
-        } else {
-          out[row * k + o] = Li[e] == 0x7fffffff ? -1 : (int64_t)Li[e];
-        }
-      }
-    }
-  }
+  et_finish_lists<KK>(Ls, Li, k, h, row, nrows, partial, out);
 }
 
 // out[r, :] = the k best of the S sorted partial lists of row r (score descending, item ascending
