@@ -12,7 +12,7 @@ u, i = make_interactions_torch(NU, NI, 47.0, seed=1234, device=dev)
 data = CDAEInteractions.from_interactions(u, i, NU, NI, seed=1, device=dev)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 cfg = make_config("CDAE", hidden_size=128, device="cuda", model_dir="/tmp/yr_cdae_epoch", lr=1e-4, batch_size=B,
-                  eval_batch_group=int(os.environ.get("YR_GROUP", "16")),
+                  eval_batch_group=int(os.environ.get("YR_GROUP", "32")),
                   negative_sampling=True, neg_times=5, loss_name="bce", top_n=10)
 trainer = CDAETrainer(cfg, NI, NU)
 form = sys.argv[2] if len(sys.argv) > 2 else "lists"
